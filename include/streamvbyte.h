@@ -1,0 +1,77 @@
+/*
+ * streamvbyte.h -- StreamVByte codec, MI355X (gfx950) implementation.
+ *
+ * Source- and link-compatible with the header of the same name in
+ * lemire/streamvbyte (reference: include/streamvbyte.h).  Every function here
+ * keeps the reference's signature, return value and byte-exact stream format;
+ * the work is done by HIP kernels in libstreamvbyte.so.2.
+ *
+ * Pointers may be host pointers (the library stages them through device
+ * memory) or device pointers from hipMalloc (used in place, no copies).
+ *
+ * Stream layout for `length` values: (length+3)/4 control bytes, then the data
+ * bytes.  `length` itself is not stored.
+ */
+#ifndef INCLUDE_STREAMVBYTE_H_
+#define INCLUDE_STREAMVBYTE_H_
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Decoders may read, never use, this many bytes past the end of a stream;
+ * encoders need this much slack after the worst-case stream.
+ * (reference: include/streamvbyte.h:12) */
+#define STREAMVBYTE_PADDING 16
+
+/* Encode `length` uint32 from `in` into `out` using 1,2,3 or 4 data bytes per
+ * value.  Returns bytes written.  `out` needs no alignment and must hold
+ * streamvbyte_max_compressedbytes(length) bytes.
+ * (replaces reference include/streamvbyte.h:23) */
+size_t streamvbyte_encode(const uint32_t *in, uint32_t length, uint8_t *out);
+
+/* As streamvbyte_encode with 0,1,2 or 4 data bytes per value.
+ * (replaces reference include/streamvbyte.h:27) */
+size_t streamvbyte_encode_0124(const uint32_t *in, uint32_t length, uint8_t *out);
+
+/* Worst-case stream size including STREAMVBYTE_PADDING.
+ * (same arithmetic as reference include/streamvbyte.h:33-39) */
+static inline size_t streamvbyte_max_compressedbytes(const uint32_t length) {
+  return ((size_t)length + 3) / 4 + (size_t)length * sizeof(uint32_t) + STREAMVBYTE_PADDING;
+}
+
+/* Exact stream size streamvbyte_encode would produce (padding not included).
+ * (replaces reference include/streamvbyte.h:47) */
+size_t streamvbyte_compressedbytes(const uint32_t *in, uint32_t length);
+
+/* Exact stream size streamvbyte_encode_0124 would produce.
+ * (replaces reference include/streamvbyte.h:55) */
+size_t streamvbyte_compressedbytes_0124(const uint32_t *in, uint32_t length);
+
+/* Decode `length` values from `in` into `out`; returns bytes consumed.  `in`
+ * needs no alignment and must be readable STREAMVBYTE_PADDING bytes past the
+ * stream.  Writes exactly length*4 bytes.
+ * (replaces reference include/streamvbyte.h:64) */
+size_t streamvbyte_decode(const uint8_t *in, uint32_t *out, uint32_t length);
+
+/* Decoder for streamvbyte_encode_0124 streams.
+ * (replaces reference include/streamvbyte.h:68) */
+size_t streamvbyte_decode_0124(const uint8_t *in, uint32_t *out, uint32_t length);
+
+/* True iff the control bytes of an `outLength`-value stream account for exactly
+ * `inLength` bytes.  Reads control bytes only.
+ * (replaces reference include/streamvbyte.h:75) */
+bool streamvbyte_validate_stream(const uint8_t *in, size_t inLength, uint32_t outLength);
+
+/* Same for 0124 streams.  (replaces reference include/streamvbyte.h:79) */
+bool streamvbyte_validate_stream_0124(const uint8_t *in, size_t inLength, uint32_t outLength);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* INCLUDE_STREAMVBYTE_H_ */

@@ -1,0 +1,125 @@
+/*
+ * streamvbyte_gpu.h -- device-pointer entry points of libstreamvbyte.so.2.
+ *
+ * These are the calls a GPU-resident caller binds instead of the host-pointer
+ * functions of streamvbyte.h.  Plain C ABI: raw device pointers, sizes, an
+ * opaque stream handle (a hipStream_t passed as void*, NULL = default stream).
+ * All work is enqueued on `stream` and returns without synchronising; results
+ * that the host-pointer API returns by value (bytes written / consumed, sizes,
+ * validity) are written to device words the caller supplies.
+ *
+ * Every function returns SVBGPU_OK or a negative SVBGPU_E* code and never
+ * falls back to a CPU implementation.
+ *
+ * Buffer rules are the reference's (include/streamvbyte.h:12-63 there):
+ * encoder output holds streamvbyte_max_compressedbytes(count) bytes, decoder
+ * input is readable 16 bytes past the stream, byte pointers need no alignment,
+ * uint32 pointers are 4-byte aligned.
+ */
+#ifndef INCLUDE_STREAMVBYTE_GPU_H_
+#define INCLUDE_STREAMVBYTE_GPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVBGPU_1234 0 /* code c -> c+1 data bytes        (streamvbyte_encode)      */
+#define SVBGPU_0124 1 /* code c -> (1<<c)>>1 data bytes   (streamvbyte_encode_0124) */
+
+#define SVBGPU_DELTA 1u  /* differential coding, uint32 wrap-around, seeded with prev */
+#define SVBGPU_ZIGZAG 2u /* encode: values are int32, zigzag-mapped before coding;
+                            decode: un-zigzag after decoding (fuses zigzag_encode/
+                            zigzag_decode into the codec pass)                      */
+
+#define SVBGPU_OK 0
+#define SVBGPU_EINVAL (-1)     /* bad argument                                   */
+#define SVBGPU_ENODEVICE (-2)  /* no usable gfx950 device                        */
+#define SVBGPU_EWORKSPACE (-3) /* workspace missing or too small                 */
+#define SVBGPU_EHIP (-4)       /* a HIP runtime call failed                      */
+#define SVBGPU_ESCAN (-5)      /* device scan did not converge (reported by
+                                  svbgpu_check_status)                           */
+
+const char *svbgpu_strerror(int code);
+
+/* 1 when the current HIP device is a gfx950 the library can run on. */
+int svbgpu_device_ok(void);
+
+/* Device scratch any single-stream call below needs for `count` values.
+ * The workspace must be 256-byte aligned; its contents are undefined between
+ * calls, and two calls that share a workspace must be ordered on one stream. */
+size_t svbgpu_workspace_bytes(uint32_t count);
+
+/* After a stream synchronisation: SVBGPU_OK, or SVBGPU_ESCAN if a kernel that
+ * used this workspace gave up waiting on another workgroup (never observed in
+ * a correct run; bounded so that a bug cannot hang the device). */
+int svbgpu_check_status(const void *d_workspace, void *stream);
+
+/* Device-pointer form of streamvbyte_decode / _decode_0124 /
+ * streamvbyte_delta_decode (reference include/streamvbyte.h:64,68,
+ * include/streamvbytedelta.h:29).  d_consumed (optional) receives the bytes
+ * consumed = the reference's return value. */
+int svbgpu_decode(int variant, unsigned flags, const uint8_t *d_in, uint32_t *d_out,
+                  uint32_t count, uint32_t prev, void *d_workspace, size_t workspace_bytes,
+                  uint64_t *d_consumed, void *stream);
+
+/* Device-pointer form of streamvbyte_encode / _encode_0124 /
+ * streamvbyte_delta_encode (reference include/streamvbyte.h:23,27,
+ * include/streamvbytedelta.h:19).  d_written (optional) receives the bytes
+ * written = the reference's return value.  Bytes of d_out past that count and
+ * inside streamvbyte_max_compressedbytes(count) are unspecified. */
+int svbgpu_encode(int variant, unsigned flags, const uint32_t *d_in, uint32_t count,
+                  uint8_t *d_out, uint32_t prev, void *d_workspace, size_t workspace_bytes,
+                  uint64_t *d_written, void *stream);
+
+/* Device-pointer form of streamvbyte_compressedbytes / _0124 (reference
+ * include/streamvbyte.h:47,55); with SVBGPU_DELTA / SVBGPU_ZIGZAG the size the
+ * matching svbgpu_encode call would produce.  *d_bytes receives the size. */
+int svbgpu_compressedbytes(int variant, unsigned flags, const uint32_t *d_in, uint32_t count,
+                           uint32_t prev, uint64_t *d_bytes, void *stream);
+
+/* Device-pointer form of streamvbyte_validate_stream / _0124 (reference
+ * include/streamvbyte.h:75,79).  *d_ok receives 1 or 0.  Reads only the
+ * (count+3)/4 control bytes, and none when they do not fit in in_length.
+ * Needs 256 bytes of workspace. */
+int svbgpu_validate(int variant, const uint8_t *d_in, uint64_t in_length, uint32_t count,
+                    uint32_t *d_ok, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Device-pointer forms of the zigzag maps (reference
+ * include/streamvbyte_zigzag.h:14,19,24,29).  The delta decode needs a
+ * workspace of svbgpu_workspace_bytes(min(n, UINT32_MAX)). */
+int svbgpu_zigzag_encode(const int32_t *d_in, uint32_t *d_out, size_t n, void *stream);
+int svbgpu_zigzag_decode(const uint32_t *d_in, int32_t *d_out, size_t n, void *stream);
+int svbgpu_zigzag_delta_encode(const int32_t *d_in, uint32_t *d_out, size_t n, int32_t prev,
+                               void *stream);
+int svbgpu_zigzag_delta_decode(const uint32_t *d_in, int32_t *d_out, size_t n, int32_t prev,
+                               void *d_workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Batched entry points: `nstreams` independent streams in one launch (posting
+ * lists, gradient chunks).  No counterpart in the reference, whose callers loop
+ * over streamvbyte_encode/decode one stream at a time (e.g. reference
+ * tests/unit.c:99-173).  Stream s has d_counts[s] values, seed d_prev[s]
+ * (d_prev may be NULL = all zero; ignored without SVBGPU_DELTA), its integers
+ * at d_values + d_value_off[s] (offset in elements) and its bytes at
+ * d_bytes + d_byte_off[s].  For encode, d_byte_off[s] must leave
+ * streamvbyte_max_compressedbytes(d_counts[s]) bytes for stream s and
+ * d_sizes[s] receives the bytes written; for decode d_sizes[s] (optional)
+ * receives the bytes consumed.
+ */
+int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t *d_values,
+                        const uint64_t *d_value_off, uint8_t *d_bytes, const uint64_t *d_byte_off,
+                        const uint32_t *d_counts, const uint32_t *d_prev, uint32_t nstreams,
+                        uint64_t *d_sizes, void *stream);
+int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t *d_bytes,
+                        const uint64_t *d_byte_off, uint32_t *d_values, const uint64_t *d_value_off,
+                        const uint32_t *d_counts, const uint32_t *d_prev, uint32_t nstreams,
+                        uint64_t *d_sizes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* INCLUDE_STREAMVBYTE_GPU_H_ */

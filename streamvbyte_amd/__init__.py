@@ -1,0 +1,254 @@
+"""streamvbyte_amd -- StreamVByte codec on MI355X (gfx950).
+
+Thin Python face of libstreamvbyte.so.2.  Two layers, both calling straight
+through the C ABI:
+
+* the reference's own functions under their own names (`streamvbyte_encode`,
+  `streamvbyte_decode`, `streamvbyte_delta_encode`, ... -- reference
+  include/streamvbyte.h, streamvbytedelta.h, streamvbyte_zigzag.h), taking
+  numpy arrays (host memory) and returning what the C function returns;
+* `DeviceCodec`, the device-pointer API of include/streamvbyte_gpu.h on torch
+  CUDA(HIP) tensors: no host copies, asynchronous on torch's current stream.
+
+The HIP library is required; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import load, LIB_PATH, SIGNATURES  # noqa: F401
+
+V1234, V0124 = 0, 1
+DELTA, ZIGZAG = 1, 2
+STREAMVBYTE_PADDING = 16
+
+
+def streamvbyte_max_compressedbytes(length):
+    """reference include/streamvbyte.h:33-39"""
+    return (length + 3) // 4 + 4 * length + STREAMVBYTE_PADDING
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data if a.size else None
+
+
+# ---- host-pointer API, reference names ---------------------------------------
+def _encode(fn, values, *extra):
+    v = _np(values, np.uint32)
+    out = np.empty(streamvbyte_max_compressedbytes(v.size), dtype=np.uint8)
+    n = fn(_ptr(v), v.size, out.ctypes.data, *extra)
+    return out[:n].copy()
+
+
+def streamvbyte_encode(values):
+    return _encode(load().streamvbyte_encode, values)
+
+
+def streamvbyte_encode_0124(values):
+    return _encode(load().streamvbyte_encode_0124, values)
+
+
+def streamvbyte_delta_encode(values, prev=0):
+    return _encode(load().streamvbyte_delta_encode, values, prev)
+
+
+def _decode(fn, stream, length, *extra):
+    s = _np(stream, np.uint8)
+    padded = np.zeros(s.size + STREAMVBYTE_PADDING, dtype=np.uint8)
+    padded[: s.size] = s
+    out = np.empty(length, dtype=np.uint32)
+    used = fn(padded.ctypes.data, _ptr(out), length, *extra)
+    return out, used
+
+
+def streamvbyte_decode(stream, length):
+    return _decode(load().streamvbyte_decode, stream, length)
+
+
+def streamvbyte_decode_0124(stream, length):
+    return _decode(load().streamvbyte_decode_0124, stream, length)
+
+
+def streamvbyte_delta_decode(stream, length, prev=0):
+    return _decode(load().streamvbyte_delta_decode, stream, length, prev)
+
+
+def streamvbyte_compressedbytes(values):
+    v = _np(values, np.uint32)
+    return load().streamvbyte_compressedbytes(_ptr(v), v.size)
+
+
+def streamvbyte_compressedbytes_0124(values):
+    v = _np(values, np.uint32)
+    return load().streamvbyte_compressedbytes_0124(_ptr(v), v.size)
+
+
+def streamvbyte_validate_stream(stream, out_length, in_length=None):
+    s = _np(stream, np.uint8)
+    return bool(load().streamvbyte_validate_stream(_ptr(s), s.size if in_length is None else in_length, out_length))
+
+
+def streamvbyte_validate_stream_0124(stream, out_length, in_length=None):
+    s = _np(stream, np.uint8)
+    return bool(load().streamvbyte_validate_stream_0124(_ptr(s), s.size if in_length is None else in_length, out_length))
+
+
+def zigzag_encode(values):
+    v = _np(values, np.int32)
+    out = np.empty(v.size, dtype=np.uint32)
+    load().zigzag_encode(_ptr(v), _ptr(out), v.size)
+    return out
+
+
+def zigzag_decode(values):
+    v = _np(values, np.uint32)
+    out = np.empty(v.size, dtype=np.int32)
+    load().zigzag_decode(_ptr(v), _ptr(out), v.size)
+    return out
+
+
+def zigzag_delta_encode(values, prev=0):
+    v = _np(values, np.int32)
+    out = np.empty(v.size, dtype=np.uint32)
+    load().zigzag_delta_encode(_ptr(v), _ptr(out), v.size, prev)
+    return out
+
+
+def zigzag_delta_decode(values, prev=0):
+    v = _np(values, np.uint32)
+    out = np.empty(v.size, dtype=np.int32)
+    load().zigzag_delta_decode(_ptr(v), _ptr(out), v.size, prev)
+    return out
+
+
+class SvbError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SvbError(f"{what}: {load().svbgpu_strerror(rc).decode()} ({rc})")
+
+
+class DeviceCodec:
+    """Device-pointer API on torch tensors (include/streamvbyte_gpu.h).
+
+    Holds the workspace and the 8-byte result words; every call is enqueued on
+    torch's current stream of `device` and returns without synchronising.
+    """
+
+    def __init__(self, max_count, device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.lib = load()
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            if not self.lib.svbgpu_device_ok():
+                raise SvbError("no usable gfx950 device")
+        self.max_count = int(max_count)
+        self.ws_bytes = self.lib.svbgpu_workspace_bytes(self.max_count)
+        self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        assert self.ws.data_ptr() % 256 == 0
+        self.res = torch.zeros(8, dtype=torch.int64, device=self.device)
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _res_ptr(self, i):
+        return self.res.data_ptr() + 8 * i
+
+    def encode(self, values, out=None, variant=V1234, flags=0, prev=0):
+        """values: uint32/int32 tensor; returns (out_bytes, size_tensor[1])."""
+        torch = self.torch
+        n = values.numel()
+        assert n <= self.max_count and values.is_contiguous()
+        if out is None:
+            out = torch.empty(streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_encode(variant, flags, values.data_ptr(), n, out.data_ptr(), prev & 0xFFFFFFFF,
+                                          self.ws.data_ptr(), self.ws_bytes, self._res_ptr(0), self._stream()),
+                   "svbgpu_encode")
+        return out, self.res[0:1]
+
+    def decode(self, stream, count, out=None, variant=V1234, flags=0, prev=0):
+        """stream: uint8 tensor readable 16 B past the stream; returns (values, consumed_tensor[1])."""
+        torch = self.torch
+        assert count <= self.max_count and stream.is_contiguous()
+        if out is None:
+            out = torch.empty(count, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode(variant, flags, stream.data_ptr(), out.data_ptr(), count, prev & 0xFFFFFFFF,
+                                          self.ws.data_ptr(), self.ws_bytes, self._res_ptr(1), self._stream()),
+                   "svbgpu_decode")
+        return out, self.res[1:2]
+
+    def compressedbytes(self, values, variant=V1234, flags=0, prev=0):
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_compressedbytes(variant, flags, values.data_ptr(), values.numel(),
+                                                   prev & 0xFFFFFFFF, self._res_ptr(2), self._stream()),
+                   "svbgpu_compressedbytes")
+        return self.res[2:3]
+
+    def validate(self, stream, in_length, count, variant=V1234):
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_validate(variant, stream.data_ptr(), in_length, count, self._res_ptr(3),
+                                            self.ws.data_ptr(), self.ws_bytes, self._stream()), "svbgpu_validate")
+        return self.res[3:4]
+
+    def zigzag(self, values, mode, prev=0, out=None):
+        """mode: 'encode' | 'decode' | 'delta_encode' | 'delta_decode'"""
+        torch = self.torch
+        n = values.numel()
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+        st = self._stream()
+        with torch.cuda.device(self.device):
+            if mode == "encode":
+                rc = self.lib.svbgpu_zigzag_encode(values.data_ptr(), out.data_ptr(), n, st)
+            elif mode == "decode":
+                rc = self.lib.svbgpu_zigzag_decode(values.data_ptr(), out.data_ptr(), n, st)
+            elif mode == "delta_encode":
+                rc = self.lib.svbgpu_zigzag_delta_encode(values.data_ptr(), out.data_ptr(), n, prev, st)
+            elif mode == "delta_decode":
+                rc = self.lib.svbgpu_zigzag_delta_decode(values.data_ptr(), out.data_ptr(), n, prev,
+                                                         self.ws.data_ptr(), self.ws_bytes, st)
+            else:
+                raise ValueError(mode)
+        _check(rc, "svbgpu_zigzag_" + mode)
+        return out
+
+    def encode_batch(self, values, value_off, byte_buf, byte_off, counts, prevs=None, variant=V1234, flags=0,
+                     sizes=None):
+        torch = self.torch
+        ns = counts.numel()
+        if sizes is None:
+            sizes = torch.empty(ns, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_encode_batch(variant, flags, values.data_ptr(), value_off.data_ptr(),
+                                                byte_buf.data_ptr(), byte_off.data_ptr(), counts.data_ptr(),
+                                                prevs.data_ptr() if prevs is not None else None, ns,
+                                                sizes.data_ptr(), self._stream()), "svbgpu_encode_batch")
+        return sizes
+
+    def decode_batch(self, byte_buf, byte_off, values, value_off, counts, prevs=None, variant=V1234, flags=0,
+                     sizes=None):
+        torch = self.torch
+        ns = counts.numel()
+        if sizes is None:
+            sizes = torch.empty(ns, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode_batch(variant, flags, byte_buf.data_ptr(), byte_off.data_ptr(),
+                                                values.data_ptr(), value_off.data_ptr(), counts.data_ptr(),
+                                                prevs.data_ptr() if prevs is not None else None, ns,
+                                                sizes.data_ptr(), self._stream()), "svbgpu_decode_batch")
+        return sizes
+
+    def check(self):
+        """Synchronise and raise if a device scan gave up (never expected)."""
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_check_status(self.ws.data_ptr(), self._stream()), "svbgpu_check_status")

@@ -1,0 +1,625 @@
+// C ABI of libstreamvbyte.so.2: the device-pointer entry points of
+// include/streamvbyte_gpu.h and the reference-compatible host/device-pointer
+// functions of include/streamvbyte.h, streamvbytedelta.h, streamvbyte_zigzag.h.
+// Everything here launches HIP kernels; there is no CPU implementation of the
+// codec in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/streamvbyte.h"
+#include "../../include/streamvbyte_gpu.h"
+#include "../../include/streamvbyte_zigzag.h"
+#include "../../include/streamvbytedelta.h"
+#include "svb_decode.h"
+#include "svb_delta.h"
+#include "svb_encode.h"
+#include "svb_misc.h"
+#include "svb_batch.h"
+
+using namespace svb;
+
+#define HIP_TRY(expr)                          \
+  do {                                         \
+    hipError_t e_ = (expr);                    \
+    if (e_ != hipSuccess) {                    \
+      g_last_hip_error = e_;                   \
+      return SVBGPU_EHIP;                      \
+    }                                          \
+  } while (0)
+
+namespace {
+
+thread_local hipError_t g_last_hip_error = hipSuccess;
+
+struct DevInfo {
+  bool probed = false, ok = false;
+  int cus = 0;
+};
+DevInfo g_dev[64];
+std::mutex g_dev_mu;
+
+const DevInfo& dev_info() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) {
+    static DevInfo none;
+    return none;
+  }
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  DevInfo& I = g_dev[d];
+  if (!I.probed) {
+    hipDeviceProp_t p;
+    I.probed = true;
+    if (hipGetDeviceProperties(&p, d) == hipSuccess) {
+      I.cus = p.multiProcessorCount;
+      I.ok = std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+    }
+  }
+  return I;
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Persistent streaming grids: enough workgroups to fill every CU, no more.
+inline unsigned stream_grid(unsigned long long work_blocks, int per_cu) {
+  unsigned long long cap = (unsigned long long)dev_info().cus * per_cu;
+  if (cap == 0) cap = 2048;
+  return (unsigned)(work_blocks < cap ? (work_blocks ? work_blocks : 1) : cap);
+}
+
+inline WsHeader* ws_hdr(void* ws) { return reinterpret_cast<WsHeader*>(ws); }
+template <class T>
+inline T* ws_at(void* ws, size_t off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off);
+}
+
+int check_ws(uint32_t count, void* ws, size_t ws_bytes) {
+  if (!ws || ((uintptr_t)ws & 255u)) return SVBGPU_EWORKSPACE;
+  if (ws_bytes < ws_layout(count).total) return SVBGPU_EWORKSPACE;
+  return SVBGPU_OK;
+}
+
+// header + look-back words start every call at zero
+int clear_lookback(uint32_t count, void* ws, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  HIP_TRY(hipMemsetAsync(ws, 0, L.off_super_off, st));
+  return SVBGPU_OK;
+}
+
+// ---- offset directory -------------------------------------------------------
+int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
+  u32* super_sum = ws_at<u32>(ws, L.off_super_sum);
+  u64* super_off = ws_at<u64>(ws, L.off_super_off);
+  if (variant == SVBGPU_1234)
+    hipLaunchKernelGGL(k_key_sums<V1234>, dim3((unsigned)L.n_super), dim3(kBlock), 0, st, d_in, count,
+                       wt_rel, super_sum);
+  else
+    hipLaunchKernelGGL(k_key_sums<V0124>, dim3((unsigned)L.n_super), dim3(kBlock), 0, st, d_in, count,
+                       wt_rel, super_sum);
+  hipLaunchKernelGGL(k_scan_super, dim3(1), dim3(1024), 0, st, super_sum, super_off,
+                     (u32)L.n_super, &ws_hdr(ws)->total_data);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+template <int V, bool ZZ>
+void launch_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, void* ws,
+                   uint64_t* d_consumed, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, 7);
+  hipLaunchKernelGGL((k_decode<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
+                     ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed);
+}
+template <int V, bool ZZ>
+void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
+                         void* ws, uint64_t* d_consumed, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
+                     d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
+                     ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws), ws_at<u64>(ws, L.off_status),
+                     d_consumed);
+}
+
+// decode with the directory already in the workspace
+int run_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
+               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st) {
+  const bool zz = flags & SVBGPU_ZIGZAG, delta = flags & SVBGPU_DELTA;
+  const bool v0 = variant == SVBGPU_1234;
+  if (!delta) {
+    if (v0) { if (zz) launch_decode<V1234, true>(d_in, d_out, count, ws, d_consumed, st);
+              else    launch_decode<V1234, false>(d_in, d_out, count, ws, d_consumed, st); }
+    else    { if (zz) launch_decode<V0124, true>(d_in, d_out, count, ws, d_consumed, st);
+              else    launch_decode<V0124, false>(d_in, d_out, count, ws, d_consumed, st); }
+  } else {
+    int rc = clear_lookback(count, ws, st);
+    if (rc) return rc;
+    if (v0) { if (zz) launch_delta_decode<V1234, true>(d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode<V1234, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
+    else    { if (zz) launch_delta_decode<V0124, true>(d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode<V0124, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
+  }
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+template <int V, bool D, bool Z>
+void launch_encode(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
+                   uint64_t* d_written, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  hipLaunchKernelGGL((k_encode<V, D, Z>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count,
+                     d_out, prev, ws_hdr(ws), ws_at<u64>(ws, L.off_status), d_written);
+}
+template <int V, bool D, bool Z>
+void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* d_bytes,
+                 hipStream_t st) {
+  const unsigned grid = stream_grid(((unsigned long long)count / 4 + kBlock - 1) / kBlock / 4 + 1, 8);
+  hipLaunchKernelGGL((k_size<V, D, Z>), dim3(grid), dim3(kBlock), 0, st, d_in, count, prev, d_bytes);
+}
+
+#define DISPATCH_VDZ(fn, variant, flags, ...)                                              \
+  do {                                                                                     \
+    const bool d_ = (flags)&SVBGPU_DELTA, z_ = (flags)&SVBGPU_ZIGZAG;                      \
+    if ((variant) == SVBGPU_1234) {                                                        \
+      if (d_) { if (z_) fn<V1234, true, true>(__VA_ARGS__); else fn<V1234, true, false>(__VA_ARGS__); } \
+      else    { if (z_) fn<V1234, false, true>(__VA_ARGS__); else fn<V1234, false, false>(__VA_ARGS__); } \
+    } else {                                                                               \
+      if (d_) { if (z_) fn<V0124, true, true>(__VA_ARGS__); else fn<V0124, true, false>(__VA_ARGS__); } \
+      else    { if (z_) fn<V0124, false, true>(__VA_ARGS__); else fn<V0124, false, false>(__VA_ARGS__); } \
+    }                                                                                      \
+  } while (0)
+
+bool bad_variant(int v) { return v != SVBGPU_1234 && v != SVBGPU_0124; }
+bool bad_flags(unsigned f) { return f & ~(SVBGPU_DELTA | SVBGPU_ZIGZAG); }
+
+}  // namespace
+
+// =============================================================================
+// Device-pointer API
+// =============================================================================
+extern "C" {
+
+const char* svbgpu_strerror(int code) {
+  switch (code) {
+    case SVBGPU_OK: return "ok";
+    case SVBGPU_EINVAL: return "invalid argument";
+    case SVBGPU_ENODEVICE: return "no usable gfx950 device";
+    case SVBGPU_EWORKSPACE: return "workspace missing, misaligned or too small";
+    case SVBGPU_EHIP: return hipGetErrorString(g_last_hip_error);
+    case SVBGPU_ESCAN: return "device scan gave up waiting on another workgroup";
+    default: return "unknown error";
+  }
+}
+
+int svbgpu_device_ok(void) { return dev_info().ok ? 1 : 0; }
+
+size_t svbgpu_workspace_bytes(uint32_t count) { return ws_layout(count).total; }
+
+int svbgpu_check_status(const void* d_workspace, void* stream) {
+  if (!d_workspace) return SVBGPU_EWORKSPACE;
+  u32 err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, d_workspace, 4, hipMemcpyDeviceToHost, S(stream)));
+  HIP_TRY(hipStreamSynchronize(S(stream)));
+  return err ? SVBGPU_ESCAN : SVBGPU_OK;
+}
+
+int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
+                  uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (count == 0) {
+    if (d_consumed) HIP_TRY(hipMemsetAsync(d_consumed, 0, 8, S(stream)));
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = build_directory(variant, d_in, count, ws, S(stream));
+  if (rc) return rc;
+  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+}
+
+int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,
+                  uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_written, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (count == 0) {
+    if (d_written) HIP_TRY(hipMemsetAsync(d_written, 0, 8, S(stream)));
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = clear_lookback(count, ws, S(stream));
+  if (rc) return rc;
+  DISPATCH_VDZ(launch_encode, variant, flags, d_in, count, d_out, prev, ws, d_written, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_compressedbytes(int variant, unsigned flags, const uint32_t* d_in, uint32_t count,
+                           uint32_t prev, uint64_t* d_bytes, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags) || !d_bytes) return SVBGPU_EINVAL;
+  HIP_TRY(hipMemsetAsync(d_bytes, 0, 8, S(stream)));
+  if (count == 0) return SVBGPU_OK;
+  if (!d_in) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  DISPATCH_VDZ(launch_size, variant, flags, d_in, count, prev, d_bytes, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32_t count,
+                    uint32_t* d_ok, void* ws, size_t ws_bytes, void* stream) {
+  if (bad_variant(variant) || !d_ok) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  if (!ws || ws_bytes < sizeof(WsHeader) || ((uintptr_t)ws & 255u)) return SVBGPU_EWORKSPACE;
+  const u64 keylen = ((u64)count + 3) >> 2;
+  u64* accum = &ws_hdr(ws)->accum;
+  HIP_TRY(hipMemsetAsync(accum, 0, 8, S(stream)));
+  if (in_length != 0 && count != 0 && keylen <= in_length) {
+    if (!d_in) return SVBGPU_EINVAL;
+    const unsigned grid = stream_grid(((keylen + 15) / 16 + kBlock - 1) / kBlock, 8);
+    if (variant == SVBGPU_1234)
+      hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count, accum);
+    else
+      hipLaunchKernelGGL(k_validate_sum<V0124>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count, accum);
+  }
+  hipLaunchKernelGGL(k_validate_finish, dim3(1), dim3(64), 0, S(stream), accum, (u64)in_length, count, d_ok);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+static int zigzag_launch(int mode, const uint32_t* in, uint32_t* out, size_t n, uint32_t prev,
+                         void* stream) {
+  if (n == 0) return SVBGPU_OK;
+  if (!in || !out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = stream_grid(((unsigned long long)n / 4 + kBlock - 1) / kBlock / 4 + 1, 8);
+  if (mode == 0) hipLaunchKernelGGL(k_zigzag<0>, dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+  else if (mode == 1) hipLaunchKernelGGL(k_zigzag<1>, dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+  else hipLaunchKernelGGL(k_zigzag<2>, dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_zigzag_encode(const int32_t* d_in, uint32_t* d_out, size_t n, void* stream) {
+  return zigzag_launch(0, reinterpret_cast<const uint32_t*>(d_in), d_out, n, 0, stream);
+}
+int svbgpu_zigzag_decode(const uint32_t* d_in, int32_t* d_out, size_t n, void* stream) {
+  return zigzag_launch(1, d_in, reinterpret_cast<uint32_t*>(d_out), n, 0, stream);
+}
+int svbgpu_zigzag_delta_encode(const int32_t* d_in, uint32_t* d_out, size_t n, int32_t prev,
+                               void* stream) {
+  return zigzag_launch(2, reinterpret_cast<const uint32_t*>(d_in), d_out, n, (uint32_t)prev, stream);
+}
+int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, int32_t prev,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (n == 0) return SVBGPU_OK;
+  if (!d_in || !d_out || n > 0xFFFFFFFFull) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const uint32_t count = (uint32_t)n;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = clear_lookback(count, ws, S(stream));
+  if (rc) return rc;
+  const WsLayout L = ws_layout(count);
+  hipLaunchKernelGGL(k_running_sum<true>, dim3((unsigned)L.n_tiles), dim3(kBlock), 0, S(stream), d_in,
+                     reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, ws_hdr(ws),
+                     ws_at<u64>(ws, L.off_status));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t* d_values,
+                        const uint64_t* d_value_off, uint8_t* d_bytes, const uint64_t* d_byte_off,
+                        const uint32_t* d_counts, const uint32_t* d_prev, uint32_t nstreams,
+                        uint64_t* d_sizes, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (nstreams == 0) return SVBGPU_OK;
+  if (!d_values || !d_value_off || !d_bytes || !d_byte_off || !d_counts || !d_sizes) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = stream_grid(((unsigned long long)nstreams + kWaves - 1) / kWaves, 8);
+  DISPATCH_VDZ(launch_encode_batch, variant, flags, grid, d_values, d_value_off, d_bytes, d_byte_off,
+               d_counts, d_prev, nstreams, d_sizes, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, const uint64_t* d_byte_off,
+                        uint32_t* d_values, const uint64_t* d_value_off, const uint32_t* d_counts,
+                        const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (nstreams == 0) return SVBGPU_OK;
+  if (!d_bytes || !d_byte_off || !d_values || !d_value_off || !d_counts) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = stream_grid(((unsigned long long)nstreams + kWaves - 1) / kWaves, 8);
+  DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, d_bytes, d_byte_off, d_values, d_value_off,
+               d_counts, d_prev, nstreams, d_sizes, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================
+// Reference-compatible API (host or device pointers)
+// =============================================================================
+namespace {
+
+[[noreturn]] void die(const char* what, int rc) {
+  std::fprintf(stderr, "libstreamvbyte (gfx950): %s failed: %s\n", what, svbgpu_strerror(rc));
+  std::abort();
+}
+#define HIP_OR_DIE(expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      std::fprintf(stderr, "libstreamvbyte (gfx950): %s: %s\n", #expr, hipGetErrorString(e_)); \
+      std::abort();                                                                   \
+    }                                                                                 \
+  } while (0)
+
+// Per-call scratch, recycled through a pool so concurrent callers never share
+// a stream or a buffer (the reference API is re-entrant; this keeps it so).
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* ws = nullptr;      size_t ws_cap = 0;
+  void* a = nullptr;       size_t a_cap = 0;   // staged input
+  void* b = nullptr;       size_t b_cap = 0;   // staged output
+  uint64_t* d_res = nullptr;                    // 64 bytes of device results
+  uint64_t* h_res = nullptr;                    // pinned mirror
+};
+std::mutex g_pool_mu;
+std::vector<Ctx*> g_pool;
+
+Ctx* ctx_acquire() {
+  int d = 0;
+  HIP_OR_DIE(hipGetDevice(&d));
+  if (!dev_info().ok) die("device probe", SVBGPU_ENODEVICE);
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i]->device == d) {
+        Ctx* c = g_pool[i];
+        g_pool.erase(g_pool.begin() + i);
+        return c;
+      }
+  }
+  Ctx* c = new Ctx;
+  c->device = d;
+  HIP_OR_DIE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_OR_DIE(hipMalloc(&c->d_res, 64));
+  HIP_OR_DIE(hipHostMalloc(&c->h_res, 64, hipHostMallocDefault));
+  return c;
+}
+void ctx_release(Ctx* c) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool.push_back(c);
+}
+struct CtxGuard {
+  Ctx* c;
+  CtxGuard() : c(ctx_acquire()) {}
+  ~CtxGuard() { ctx_release(c); }
+};
+
+void grow(void*& p, size_t& cap, size_t need) {
+  if (need <= cap) return;
+  if (p) HIP_OR_DIE(hipFree(p));
+  size_t n = need + need / 4 + 4096;
+  HIP_OR_DIE(hipMalloc(&p, n));
+  cap = n;
+}
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory: clear the sticky error
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+uint64_t fetch_u64(Ctx* c, const uint64_t* d_word) {
+  HIP_OR_DIE(hipMemcpyAsync(c->h_res, d_word, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_OR_DIE(hipStreamSynchronize(c->stream));
+  return c->h_res[0];
+}
+void check_scan(Ctx* c) {
+  int rc = svbgpu_check_status(c->ws, c->stream);
+  if (rc) die("device scan", rc);
+}
+
+size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t count, uint8_t* out,
+                  uint32_t prev) {
+  if (count == 0) return 0;
+  CtxGuard g;
+  Ctx* c = g.c;
+  grow(c->ws, c->ws_cap, svbgpu_workspace_bytes(count));
+  const uint32_t* d_in = in;
+  if (!is_device_ptr(in)) {
+    grow(c->a, c->a_cap, (size_t)count * 4);
+    HIP_OR_DIE(hipMemcpyAsync(c->a, in, (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    d_in = static_cast<const uint32_t*>(c->a);
+  }
+  const bool out_dev = is_device_ptr(out);
+  uint8_t* d_out = out;
+  if (!out_dev) {
+    grow(c->b, c->b_cap, streamvbyte_max_compressedbytes(count));
+    d_out = static_cast<uint8_t*>(c->b);
+  }
+  int rc = svbgpu_encode(variant, flags, d_in, count, d_out, prev, c->ws, c->ws_cap, c->d_res, c->stream);
+  if (rc) die("encode", rc);
+  const uint64_t n = fetch_u64(c, c->d_res);
+  check_scan(c);
+  if (!out_dev) {
+    HIP_OR_DIE(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_OR_DIE(hipStreamSynchronize(c->stream));
+  }
+  return (size_t)n;
+}
+
+size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out, uint32_t count,
+                  uint32_t prev) {
+  if (count == 0) return 0;
+  CtxGuard g;
+  Ctx* c = g.c;
+  grow(c->ws, c->ws_cap, svbgpu_workspace_bytes(count));
+  const size_t keylen = ((size_t)count + 3) / 4;
+  const uint8_t* d_in = in;
+  int rc;
+  if (!is_device_ptr(in)) {
+    // The stream's length is not known up front: stage the keys, let the
+    // device sum them, then stage exactly the data bytes they promise.
+    grow(c->a, c->a_cap, keylen + 16);
+    HIP_OR_DIE(hipMemcpyAsync(c->a, in, keylen, hipMemcpyHostToDevice, c->stream));
+    rc = build_directory(variant, static_cast<const uint8_t*>(c->a), count, c->ws, c->stream);
+    if (rc) die("decode (key scan)", rc);
+    const uint64_t total = fetch_u64(c, &ws_hdr(c->ws)->total_data);
+    if (c->a_cap < keylen + total + 16) {
+      grow(c->a, c->a_cap, keylen + total + 16);
+      HIP_OR_DIE(hipMemcpyAsync(c->a, in, keylen + total, hipMemcpyHostToDevice, c->stream));
+    } else {
+      HIP_OR_DIE(hipMemcpyAsync(static_cast<uint8_t*>(c->a) + keylen, in + keylen, total,
+                                hipMemcpyHostToDevice, c->stream));
+    }
+    d_in = static_cast<const uint8_t*>(c->a);
+  } else {
+    rc = build_directory(variant, d_in, count, c->ws, c->stream);
+    if (rc) die("decode (key scan)", rc);
+  }
+  const bool out_dev = is_device_ptr(out);
+  uint32_t* d_out = out;
+  if (!out_dev) {
+    grow(c->b, c->b_cap, (size_t)count * 4);
+    d_out = static_cast<uint32_t*>(c->b);
+  }
+  rc = run_decode(variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream);
+  if (rc) die("decode", rc);
+  if (!out_dev)
+    HIP_OR_DIE(hipMemcpyAsync(out, d_out, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+  const uint64_t n = fetch_u64(c, c->d_res);
+  if (flags & SVBGPU_DELTA) check_scan(c);
+  return (size_t)n;
+}
+
+size_t size_any(int variant, const uint32_t* in, uint32_t count) {
+  if (count == 0) return 0;
+  CtxGuard g;
+  Ctx* c = g.c;
+  const uint32_t* d_in = in;
+  if (!is_device_ptr(in)) {
+    grow(c->a, c->a_cap, (size_t)count * 4);
+    HIP_OR_DIE(hipMemcpyAsync(c->a, in, (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    d_in = static_cast<const uint32_t*>(c->a);
+  }
+  int rc = svbgpu_compressedbytes(variant, 0, d_in, count, 0, c->d_res, c->stream);
+  if (rc) die("compressedbytes", rc);
+  return (size_t)fetch_u64(c, c->d_res);
+}
+
+bool validate_any(int variant, const uint8_t* in, size_t in_length, uint32_t count) {
+  // empty rules need no device work (reference src/streamvbyte_decode.c:91-92)
+  if (in_length == 0 || count == 0) return in_length == (size_t)count;
+  const size_t keylen = ((size_t)count + 3) / 4;
+  if (keylen > in_length) return false;
+  CtxGuard g;
+  Ctx* c = g.c;
+  grow(c->ws, c->ws_cap, sizeof(WsHeader));
+  const uint8_t* d_in = in;
+  if (!is_device_ptr(in)) {
+    grow(c->a, c->a_cap, keylen + 16);
+    HIP_OR_DIE(hipMemcpyAsync(c->a, in, keylen, hipMemcpyHostToDevice, c->stream));
+    d_in = static_cast<const uint8_t*>(c->a);
+  }
+  int rc = svbgpu_validate(variant, d_in, in_length, count, reinterpret_cast<uint32_t*>(c->d_res + 1),
+                           c->ws, c->ws_cap, c->stream);
+  if (rc) die("validate_stream", rc);
+  HIP_OR_DIE(hipMemcpyAsync(c->h_res, c->d_res + 1, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_OR_DIE(hipStreamSynchronize(c->stream));
+  return (reinterpret_cast<uint32_t*>(c->h_res)[0]) != 0;
+}
+
+void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
+  if (n == 0) return;
+  CtxGuard g;
+  Ctx* c = g.c;
+  const bool in_dev = is_device_ptr(in), out_dev = is_device_ptr(out);
+  const void* d_in = in;
+  void* d_out = out;
+  if (!in_dev) {
+    grow(c->a, c->a_cap, n * 4);
+    HIP_OR_DIE(hipMemcpyAsync(c->a, in, n * 4, hipMemcpyHostToDevice, c->stream));
+    d_in = c->a;
+  }
+  if (!out_dev) {
+    grow(c->b, c->b_cap, n * 4);
+    d_out = c->b;
+  }
+  int rc;
+  if (mode == 3) {
+    if (n > 0xFFFFFFFFull) die("zigzag_delta_decode (N >= 2^32)", SVBGPU_EINVAL);
+    grow(c->ws, c->ws_cap, svbgpu_workspace_bytes((uint32_t)n));
+    rc = svbgpu_zigzag_delta_decode(static_cast<const uint32_t*>(d_in), static_cast<int32_t*>(d_out),
+                                    n, prev, c->ws, c->ws_cap, c->stream);
+  } else {
+    rc = zigzag_launch(mode, static_cast<const uint32_t*>(d_in), static_cast<uint32_t*>(d_out), n,
+                       (uint32_t)prev, c->stream);
+  }
+  if (rc) die("zigzag", rc);
+  if (!out_dev) HIP_OR_DIE(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_OR_DIE(hipStreamSynchronize(c->stream));
+  if (mode == 3) check_scan(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t streamvbyte_encode(const uint32_t* in, uint32_t length, uint8_t* out) {
+  return encode_any(SVBGPU_1234, 0, in, length, out, 0);
+}
+size_t streamvbyte_encode_0124(const uint32_t* in, uint32_t length, uint8_t* out) {
+  return encode_any(SVBGPU_0124, 0, in, length, out, 0);
+}
+size_t streamvbyte_compressedbytes(const uint32_t* in, uint32_t length) {
+  return size_any(SVBGPU_1234, in, length);
+}
+size_t streamvbyte_compressedbytes_0124(const uint32_t* in, uint32_t length) {
+  return size_any(SVBGPU_0124, in, length);
+}
+size_t streamvbyte_decode(const uint8_t* in, uint32_t* out, uint32_t length) {
+  return decode_any(SVBGPU_1234, 0, in, out, length, 0);
+}
+size_t streamvbyte_decode_0124(const uint8_t* in, uint32_t* out, uint32_t length) {
+  return decode_any(SVBGPU_0124, 0, in, out, length, 0);
+}
+bool streamvbyte_validate_stream(const uint8_t* in, size_t inLength, uint32_t outLength) {
+  return validate_any(SVBGPU_1234, in, inLength, outLength);
+}
+bool streamvbyte_validate_stream_0124(const uint8_t* in, size_t inLength, uint32_t outLength) {
+  return validate_any(SVBGPU_0124, in, inLength, outLength);
+}
+size_t streamvbyte_delta_encode(const uint32_t* in, uint32_t length, uint8_t* out, uint32_t prev) {
+  return encode_any(SVBGPU_1234, SVBGPU_DELTA, in, length, out, prev);
+}
+size_t streamvbyte_delta_decode(const uint8_t* in, uint32_t* out, uint32_t length, uint32_t prev) {
+  return decode_any(SVBGPU_1234, SVBGPU_DELTA, in, out, length, prev);
+}
+void zigzag_encode(const int32_t* in, uint32_t* out, size_t N) { zigzag_any(0, in, out, N, 0); }
+void zigzag_decode(const uint32_t* in, int32_t* out, size_t N) { zigzag_any(1, in, out, N, 0); }
+void zigzag_delta_encode(const int32_t* in, uint32_t* out, size_t N, int32_t prev) {
+  zigzag_any(2, in, out, N, prev);
+}
+void zigzag_delta_decode(const uint32_t* in, int32_t* out, size_t N, int32_t prev) {
+  zigzag_any(3, in, out, N, prev);
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// Decode path: offset directory (key sums + scan) and the decode kernel.
+//
+// Replaces the serial `dataPtr += lengthTable[key]` chain of the reference
+// (src/streamvbyte_x64_decode.c:10-26,39-112; scalar src/streamvbyte_decode.c:18-60;
+// 0124 twin src/streamvbyte_0124_decode.c:17-27,38-79,83-157) with prefix sums.
+#pragma once
+#include "svb_device.h"
+
+namespace svb {
+
+// ---------------------------------------------------------------------------
+// k_key_sums: one workgroup per super tile (64 wave tiles = 16384 keys).
+// Thread t, round i reads the 16 keys at i*4096 + 16*t, so every 16 lanes cover
+// one wave tile; a 16-lane reduction gives the wave tile's data bytes.  Wave 0
+// then scans the 64 sums: wt_rel[] = data offset of each wave tile inside its
+// super tile, super_sum[] = data bytes of the super tile.
+// Reads 0.25 B per value, writes 4 B per 1024 values.
+template <int V>
+__global__ __launch_bounds__(kBlock) void k_key_sums(const u8* __restrict__ in, u32 count,
+                                                     u32* __restrict__ wt_rel,
+                                                     u32* __restrict__ super_sum) {
+  __shared__ u32 s_sum[kSuperWt];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u64 n_wt = (keylen + kWtKeys - 1) / kWtKeys;
+  const u64 key_base = (u64)blockIdx.x * (kSuperWt * kWtKeys);
+  const int t = threadIdx.x;
+
+  uint4 k[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u64 koff = key_base + (u64)i * 4096 + 16 * t;
+    k[i] = make_uint4(0, 0, 0, 0);
+    if (koff < keylen) k[i] = ld_u128(in + koff);  // may overrun the keys by <16 B: data or padding
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u64 koff = key_base + (u64)i * 4096 + 16 * t;
+    const u64 first = koff * 4;
+    u32 nv = first < count ? (u32)min((u64)64, (u64)count - first) : 0u;  // valid values, 0..64
+    const u32 w[4] = {k[i].x, k[i].y, k[i].z, k[i].w};
+    u32 s = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
+      s += word_len<V>(mask_codes(w[d], nvd), nvd);
+    }
+    // reduce over the 16 lanes that share a wave tile
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if ((t & 15) == 0) s_sum[i * 16 + (t >> 4)] = s;
+  }
+  __syncthreads();
+  if (t < 64) {
+    const u32 x = s_sum[t];
+    const u32 incl = wave_scan_incl(x, t);
+    const u64 wt = (u64)blockIdx.x * kSuperWt + t;
+    if (wt < n_wt) wt_rel[wt] = incl - x;
+    if (t == 63) super_sum[blockIdx.x] = incl;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_scan_super: exclusive 64-bit scan of the super tile sums by one workgroup.
+// super_off[i] = data bytes before super tile i; super_off[n] = total.
+__global__ __launch_bounds__(1024) void k_scan_super(const u32* __restrict__ super_sum,
+                                                     u64* __restrict__ super_off, u32 n,
+                                                     u64* __restrict__ total_out) {
+  __shared__ u64 s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u32 per = (n + 1023) / 1024;
+  const u32 lo = min(n, t * per), hi = min(n, lo + per);
+  u64 mine = 0;
+  for (u32 i = lo; i < hi; ++i) mine += super_sum[i];
+  // wave scan on 64-bit values
+  u64 x = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u64 y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  u64 base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  u64 run = base + x - mine;
+  for (u32 i = lo; i < hi; ++i) {
+    super_off[i] = run;
+    run += super_sum[i];
+  }
+  if (t == 1023) {
+    super_off[n] = run;
+    if (total_out) *total_out = run;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Per-wave LDS: 256 entries (data offset | key<<16) + the wave tile's data span.
+struct __align__(16) WaveLds {
+  u32 ent[kWtKeys];
+  u8 data[kWtDataMax + 48];  // +16 alignment slack, +16 partial chunk, +slack for 4-byte over-read
+};
+
+// Blocked phase: lane holds keys 4l..4l+3 in w.  Writes the 4 entries of those
+// keys and returns the wave tile's data byte count.
+template <int V>
+__device__ __forceinline__ u32 scan_keys_to_entries(u32 w, u32 nv, int lane, u32* ent) {
+  w = mask_codes(w, nv);
+  const u32 L = key_lens4<V>(w, nv);                 // 4 packed lengths
+  const u32 tot = (L * 0x01010101u) >> 24;            // their sum (<= 64)
+  const u32 P = L * 0x01010100u;                      // packed exclusive prefix inside the lane
+  const u32 incl = wave_scan_incl(tot, lane);
+  const u32 ex = incl - tot;
+  uint4 e;
+  e.x = (ex) | ((w & 0xFFu) << 16);
+  e.y = (ex + ((P >> 8) & 0xFFu)) | (((w >> 8) & 0xFFu) << 16);
+  e.z = (ex + ((P >> 16) & 0xFFu)) | (((w >> 16) & 0xFFu) << 16);
+  e.w = (ex + (P >> 24)) | ((w >> 24) << 16);
+  *reinterpret_cast<uint4*>(ent + 4 * lane) = e;
+  return __shfl(incl, 63, 64);
+}
+
+// Stage the contiguous data span [dp, dp+total) into LDS with aligned 16-byte
+// loads.  Returns the offset of dp's first byte inside the LDS image.
+__device__ __forceinline__ u32 stage_span(const u8* dp, u32 total, int lane, u8* sdata) {
+  const u32 shift = (u32)((uintptr_t)dp & 15u);
+  const uint4* src = reinterpret_cast<const uint4*>(dp - shift);
+  const u32 nch = (shift + total + 15u) >> 4;  // <= 257
+  // Issue every load before the first LDS write so that up to five are in
+  // flight.  Lanes past the end re-read the last chunk (same cache line) so
+  // that the loads stay unconditional within a wave-uniform branch.
+  uint4 r[5];
+  const u32 last = nch - 1u;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    r[i] = make_uint4(0, 0, 0, 0);
+    if (64u * i < nch) r[i] = src[min((u32)lane + 64u * i, last)];
+  }
+  uint4* d = reinterpret_cast<uint4*>(sdata);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const u32 c = lane + 64u * i;
+    if (c < nch) d[c] = r[i];
+  }
+  return shift;
+}
+
+// Striped phase: decode group g = j*64 + lane from the LDS image.
+template <int V>
+__device__ __forceinline__ uint4 extract_group(u32 entry, u32 shift, const u8* sdata) {
+  const u32 key = entry >> 16;
+  u32 p = (entry & 0xFFFFu) + shift;
+  u32 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32 c = (key >> (2 * k)) & 3u;
+    v[k] = lds_u32(sdata + p) & mask_of<V>(c);
+    p += len_of<V>(c);
+  }
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// One wave tile, keys -> values: lane ends up with the (up to) 4 groups
+// j*64+lane, j = 0..3, of the wave tile whose keys it holds blocked in `w`.
+// Values past `nints` are returned as zero.  Returns the tile's data bytes.
+template <int V, bool ZZ>
+__device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, int lane, WaveLds& S,
+                                               uint4 (&v)[4]) {
+  const u32 nv = nints > 16u * lane ? min(nints - 16u * lane, 16u) : 0u;
+  const u32 total = scan_keys_to_entries<V>(w, nv, lane, S.ent);
+  const u32 shift = stage_span(dp, total, lane, S.data);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 first = 4u * (j * 64 + lane);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (first < nints) {
+      r = extract_group<V>(S.ent[j * 64 + lane], shift, S.data);
+      if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
+      const u32 left = nints - first;
+      if (left < 4) { r.w = 0; if (left < 3) r.z = 0; if (left < 2) r.y = 0; }
+    }
+    v[j] = r;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return total;
+}
+
+// Store group `first..first+3` of a stream of `count` values.
+__device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, const uint4& v) {
+  if (first + 4 <= count) {
+    __builtin_memcpy(out + first, &v, 16);
+  } else if (first < count) {
+    out[first] = v.x;
+    if (first + 1 < count) out[first + 1] = v.y;
+    if (first + 2 < count) out[first + 2] = v.z;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_decode: persistent waves, each loops over wave tiles (stride = waves in the
+// grid) with the next tile's keys and offset prefetched.  No inter-workgroup
+// dependency: data offsets come from the directory built by k_key_sums /
+// k_scan_super.  HBM traffic per value: 0.25 (keys) + dbar (data) + 4 (out).
+template <int V, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
+                                                   u32* __restrict__ out, u32 count,
+                                                   const u64* __restrict__ super_off,
+                                                   const u32* __restrict__ wt_rel,
+                                                   u64* __restrict__ consumed) {
+  __shared__ WaveLds s_lds[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  WaveLds& S = s_lds[wave];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u32 stride = gridDim.x * kWaves;
+  u32 wt = blockIdx.x * kWaves + wave;
+  if (wt >= n_wt) return;
+  const u8* data_base = in + keylen;
+
+  auto load_keys = [&](u32 t) -> u32 {
+    const u64 koff = (u64)t * kWtKeys + 4 * lane;
+    return koff < keylen ? ld_u32(in + koff) : 0u;
+  };
+  u32 w_next = load_keys(wt);
+  u64 off_next = super_off[wt / kSuperWt] + wt_rel[wt];
+
+  while (true) {
+    const u32 w = w_next;
+    const u64 doff = off_next;
+    const u32 wt_n = wt + stride;
+    if (wt_n < n_wt) {
+      w_next = load_keys(wt_n);
+      off_next = super_off[wt_n / kSuperWt] + wt_rel[wt_n];
+    }
+    const u64 int0 = (u64)wt * kWtInts;
+    const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
+    uint4 v[4];
+    const u32 total = decode_wavetile<V, ZZ>(w, nints, data_base + doff, lane, S, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_group(out, int0 + 4u * (j * 64 + lane), count, v[j]);
+    if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;
+    if (wt_n >= n_wt) break;
+    wt = wt_n;
+  }
+}
+
+}  // namespace svb

@@ -1,0 +1,174 @@
+// Differential decode and plain running sums: decode fused with a uint32
+// wrap-around inclusive scan seeded with the caller's prev.
+//
+// Replaces the second serial chain of the reference delta decoder
+// (src/streamvbytedelta_x64_decode.c:32-65,69-175; scalar
+// src/streamvbytedelta_decode.c:34-57) and the loop of zigzag_delta_decode
+// (src/streamvbyte_zigzag.c:32-38).
+//
+// One workgroup = one tile of 16 wave tiles (16384 values), wave w owns wave
+// tiles 4w..4w+3 and keeps its 64 decoded values per lane in registers while
+// the tile's sum travels through the decoupled look-back; data offsets come
+// from the same directory the plain decoder uses.
+#pragma once
+#include "svb_decode.h"
+#include "svb_lookback.h"
+
+namespace svb {
+
+// Turn the 16 uint4 of a wave (4 wave tiles x 4 striped groups) into running
+// sums relative to the wave's first value.  Returns the wave's total.
+__device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[4][4], int lane) {
+  u32 run = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4& c = v[q][j];
+      c.y += c.x;
+      c.z += c.y;
+      c.w += c.z;
+      const u32 incl = wave_scan_incl(c.w, lane);
+      const u32 ex = incl - c.w + run;
+      run += __shfl(incl, 63, 64);
+      c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+    }
+  return run;
+}
+
+// Workgroup-level part shared by the delta decoder and the plain scan kernel:
+// exchange wave totals, publish the tile total, look back, return the value to
+// add to every element of this wave.
+__device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 seed, int lane,
+                                                 int wave, WsHeader* hdr, u64* status,
+                                                 u32* s_wave_tot, u32* s_prefix) {
+  if (lane == 0) s_wave_tot[wave] = wave_tot;
+  __syncthreads();
+  if (wave == 0) {
+    const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    u32 excl = seed;
+    if (tile == 0) {
+      if (lane == 0) lb_publish(status, 0, kLbPfx, (u32)(seed + tile_tot));
+    } else {
+      if (lane == 0) lb_publish(status, tile, kLbAgg, tile_tot);
+      excl = (u32)lb_exclusive_prefix(status, tile, lane, &hdr->error);
+      if (lane == 0) lb_publish(status, tile, kLbPfx, (u32)(excl + tile_tot));
+    }
+    if (lane == 0) *s_prefix = excl;
+  }
+  __syncthreads();
+  u32 add = *s_prefix;
+  for (int w = 0; w < wave; ++w) add += s_wave_tot[w];
+  return add;
+}
+
+template <int V, bool ZZ>
+__global__ __launch_bounds__(kBlock, 4) void k_delta_decode(
+    const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
+    const u64* __restrict__ super_off, const u32* __restrict__ wt_rel, WsHeader* __restrict__ hdr,
+    u64* __restrict__ status, u64* __restrict__ consumed) {
+  __shared__ WaveLds s_lds[kWaves];
+  __shared__ u32 s_wave_tot[kWaves];
+  __shared__ u32 s_prefix;
+  __shared__ u32 s_tile;
+  const int lane = lane_id(), wave = wave_id();
+  if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  WaveLds& S = s_lds[wave];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u8* data_base = in + keylen;
+  const u32 wt0 = tile * kLbWt + wave * 4;
+
+  uint4 v[4][4];
+  // keys and offsets of the wave's 4 wave tiles up front
+  u32 w[4];
+  u64 doff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32 wt = wt0 + q;
+    w[q] = 0;
+    doff[q] = 0;
+    if (wt < n_wt) {
+      const u64 koff = (u64)wt * kWtKeys + 4 * lane;
+      if (koff < keylen) w[q] = ld_u32(in + koff);
+      doff[q] = super_off[wt / kSuperWt] + wt_rel[wt];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32 wt = wt0 + q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
+    if (wt < n_wt) {
+      const u64 int0 = (u64)wt * kWtInts;
+      const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
+      const u32 total = decode_wavetile<V, ZZ>(w[q], nints, data_base + doff[q], lane, S, v[q]);
+      if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + total;
+    }
+  }
+  const u32 wave_tot = wave_running_sums(v, lane);
+  const u32 add = tile_value_prefix(wave_tot, tile, prev, lane, wave, hdr, status, s_wave_tot,
+                                    &s_prefix);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 r = v[q][j];
+      r.x += add; r.y += add; r.z += add; r.w += add;
+      store_group(out, ((u64)(wt0 + q)) * kWtInts + 4u * (j * 64 + lane), count, r);
+    }
+}
+
+// Plain inclusive running sum out[i] = seed + sum_{j<=i} f(in[j]), f = identity
+// or un-zigzag (zigzag_delta_decode).  8 B per value.
+template <bool ZZ>
+__global__ __launch_bounds__(kBlock, 4) void k_running_sum(const u32* __restrict__ in,
+                                                           u32* __restrict__ out, u32 count,
+                                                           u32 seed, WsHeader* __restrict__ hdr,
+                                                           u64* __restrict__ status) {
+  __shared__ u32 s_wave_tot[kWaves];
+  __shared__ u32 s_prefix;
+  __shared__ u32 s_tile;
+  const int lane = lane_id(), wave = wave_id();
+  if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+  __syncthreads();
+  const u32 tile = s_tile;
+  const u64 wave_first = ((u64)tile * kLbWt + (u64)wave * 4) * kWtInts;
+  uint4 v[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u64 first = wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane);
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (first + 4 <= count) {
+        __builtin_memcpy(&r, in + first, 16);
+        if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
+      } else if (first < count) {
+        r.x = in[first];
+        if (first + 1 < count) r.y = in[first + 1];
+        if (first + 2 < count) r.z = in[first + 2];
+        if (ZZ) {
+          r.x = zz_dec(r.x);
+          r.y = first + 1 < count ? zz_dec(r.y) : 0u;
+          r.z = first + 2 < count ? zz_dec(r.z) : 0u;
+        }
+      }
+      v[q][j] = r;
+    }
+  const u32 wave_tot = wave_running_sums(v, lane);
+  const u32 add = tile_value_prefix(wave_tot, tile, seed, lane, wave, hdr, status, s_wave_tot,
+                                    &s_prefix);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 r = v[q][j];
+      r.x += add; r.y += add; r.z += add; r.w += add;
+      store_group(out, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count, r);
+    }
+}
+
+}  // namespace svb

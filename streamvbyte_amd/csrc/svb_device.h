@@ -1,0 +1,178 @@
+// Device-side building blocks shared by every StreamVByte kernel (gfx950 only).
+//
+// Vocabulary
+//   key        one control byte = the 2-bit codes of 4 consecutive values
+//   group      the 4 values of one key and their 0..16 data bytes
+//   wave tile  256 keys = 1024 values, the unit one 64-lane wavefront handles:
+//              lane l owns keys 4l..4l+3 while lengths are scanned ("blocked")
+//              and groups l, l+64, l+128, l+192 while bytes are moved
+//              ("striped"), so that every global access of the uint32 side is
+//              one contiguous 1 KiB per wave instruction.
+//   super tile 64 wave tiles, the unit of the two-level offset directory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svb {
+
+constexpr int V1234 = 0;
+constexpr int V0124 = 1;
+
+constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
+constexpr int kWaves = 4;
+constexpr int kWtKeys = 256;         // keys per wave tile
+constexpr int kWtInts = 1024;        // values per wave tile
+constexpr int kSuperWt = 64;         // wave tiles per super tile
+constexpr int kWtDataMax = 4096;     // data bytes of a wave tile, worst case
+
+using u8 = uint8_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() {
+  return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+}
+
+// gfx950 executes dword global and LDS accesses at any byte address.
+__device__ __forceinline__ u32 ld_u32(const u8* p) {
+  u32 v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ uint4 ld_u128(const u8* p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
+__device__ __forceinline__ u32 lds_u32(const u8* p) {
+  u32 v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wavefront.
+__device__ __forceinline__ u32 wave_scan_incl(u32 x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+__device__ __forceinline__ u32 wave_sum(u32 x) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+  return x;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 x) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+  return x;
+}
+
+// ---- width arithmetic -------------------------------------------------------
+// Width code of a value (reference src/streamvbyte_encode.c:14-37 and
+// src/streamvbyte_0124_encode.c:12-32).
+template <int V>
+__device__ __forceinline__ u32 code_of(u32 v) {
+  if (V == V1234) return (u32)(v > 0xFFu) + (u32)(v > 0xFFFFu) + (u32)(v > 0xFFFFFFu);
+  return (u32)(v != 0u) + (u32)(v > 0xFFu) + (u32)(v > 0xFFFFu);
+}
+// Data bytes of a code (reference src/streamvbyte_decode.c:22-36,
+// src/streamvbyte_0124_decode.c:210).
+template <int V>
+__device__ __forceinline__ u32 len_of(u32 c) {
+  return V == V1234 ? c + 1u : ((1u << c) >> 1);
+}
+// Mask keeping the low len_of(c) bytes.
+template <int V>
+__device__ __forceinline__ u32 mask_of(u32 c) {
+  if (V == V1234) return 0xFFFFFFFFu >> (24u - 8u * c);
+  u32 m = 0xFFFFFFFFu >> ((32u - (8u << c >> 1)) & 31u);  // c=1:>>24  c=2:>>16  c=3:>>0
+  return c ? m : 0u;
+}
+
+// Per-byte sums of the four 2-bit fields of each byte of w (SWAR).
+__device__ __forceinline__ u32 code_sums4(u32 w) {
+  u32 s = (w & 0x33333333u) + ((w >> 2) & 0x33333333u);
+  return (s + (s >> 4)) & 0x0F0F0F0Fu;
+}
+// Per-byte count of 2-bit fields equal to 3.
+__device__ __forceinline__ u32 code_threes4(u32 w) {
+  u32 t = w & (w >> 1) & 0x55555555u;
+  t = (t + (t >> 2)) & 0x33333333u;
+  return (t + (t >> 4)) & 0x0F0F0F0Fu;
+}
+// nv = number of valid values among the 16 coded by w (0..16).
+// Returns w with the codes of absent values cleared.
+__device__ __forceinline__ u32 mask_codes(u32 w, u32 nv) {
+  u32 m = nv >= 16u ? 0xFFFFFFFFu : ((1u << (2u * nv)) - 1u);
+  return w & m;
+}
+// Packed per-key count of valid values (each byte 0..4) for a lane whose 16
+// values have nv valid ones.
+__device__ __forceinline__ u32 valid_per_key4(u32 nv) {
+  if (nv >= 16u) return 0x04040404u;
+  u32 a = min(nv, 4u);
+  u32 b = min(nv - min(nv, 4u), 4u);
+  u32 c = min(nv - min(nv, 8u), 4u);
+  u32 d = min(nv - min(nv, 12u), 4u);
+  return a | (b << 8) | (c << 16) | (d << 24);
+}
+// Packed data-byte lengths (one byte per key, each 0..16) of the 4 keys in w.
+// This is the length table of the reference
+// (src/streamvbyte_shuffle_tables_decode.h:5-22, _0124_decode.h:2-19,
+// generator utils/shuffle_tables.c:10-38) evaluated arithmetically for four
+// keys at once; absent values of a final partial key count for nothing.
+template <int V>
+__device__ __forceinline__ u32 key_lens4(u32 w_masked, u32 nv) {
+  if (V == V1234) return code_sums4(w_masked) + valid_per_key4(nv);
+  return code_sums4(w_masked) + code_threes4(w_masked);
+}
+// Total data bytes of the 16 values coded by w.
+template <int V>
+__device__ __forceinline__ u32 word_len(u32 w_masked, u32 nv) {
+  u32 lo = __popc(w_masked & 0x55555555u), hi = __popc(w_masked & 0xAAAAAAAAu);
+  if (V == V1234) return nv + lo + 2u * hi;
+  return lo + 2u * hi + __popc(w_masked & (w_masked >> 1) & 0x55555555u);
+}
+
+__device__ __forceinline__ u32 zz_enc(u32 v) { return (v << 1) ^ (0u - (v >> 31)); }
+__device__ __forceinline__ u32 zz_dec(u32 v) { return (v >> 1) ^ (0u - (v & 1u)); }
+
+// ---- workspace layout ---------------------------------------------------------
+// One 256-byte header followed by the offset directory and the look-back words.
+struct WsHeader {
+  u32 error;        // set non-zero when a bounded spin gave up
+  u32 ticket;       // dynamic tile counter of the look-back kernels
+  u64 accum;        // reduction scratch (validate)
+  u64 total_data;   // total data bytes of the stream being processed
+  u32 pad[58];
+};
+static_assert(sizeof(WsHeader) == 256, "header is one 256-byte block");
+
+struct WsLayout {
+  u64 n_wt, n_super, n_tiles;
+  size_t off_super_off, off_wt_rel, off_super_sum, off_status, total;
+};
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr int kLbWt = 16;  // wave tiles per look-back tile (16384 values)
+
+__host__ __device__ inline WsLayout ws_layout(u32 count) {
+  WsLayout L;
+  u64 keylen = ((u64)count + 3) >> 2;
+  L.n_wt = (keylen + kWtKeys - 1) / kWtKeys;
+  L.n_super = (L.n_wt + kSuperWt - 1) / kSuperWt;
+  L.n_tiles = (L.n_wt + kLbWt - 1) / kLbWt;
+  size_t o = sizeof(WsHeader);
+  // the look-back words follow the header so one memset clears both
+  L.off_status = o;    o += align256(8 * (L.n_tiles + 1));
+  L.off_super_off = o; o += align256(8 * (L.n_super + 1));
+  L.off_wt_rel = o;    o += align256(4 * L.n_wt);
+  L.off_super_sum = o; o += align256(4 * L.n_super);
+  L.total = o;
+  return L;
+}
+
+}  // namespace svb

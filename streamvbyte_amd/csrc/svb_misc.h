@@ -1,0 +1,144 @@
+// Reductions and element-wise maps: exact size, stream validation, zigzag.
+#pragma once
+#include "svb_device.h"
+
+namespace svb {
+
+// Block-wide sum of a 64-bit value, result valid in thread 0.
+__device__ __forceinline__ u64 block_sum64(u64 x, u64* s_tmp) {
+  x = wave_sum64(x);
+  if (lane_id() == 0) s_tmp[threadIdx.x >> 6] = x;
+  __syncthreads();
+  u64 r = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += s_tmp[w];
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// k_size: exact stream size = keyLen + sum of widths (reference
+// src/streamvbyte_encode.c:69-108, src/streamvbyte_x64_encode.c:33-51).
+// With DELTA the widths are those of in[i]-in[i-1]; ZZ zigzag-maps the value
+// (or the difference) first.
+// *result must be zero before the launch.  Reads 4 B per value.
+template <int V, bool DELTA, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32 count, u32 prev,
+                                                 u64* __restrict__ result) {
+  __shared__ u64 s_tmp[kWaves];
+  const u64 nquads = (u64)count >> 2;
+  u64 acc = 0;
+  for (u64 q = (u64)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (u64)gridDim.x * kBlock) {
+    uint4 x;
+    __builtin_memcpy(&x, in + 4 * q, 16);
+    u32 v[4] = {x.x, x.y, x.z, x.w};
+    if (DELTA) {
+      const u32 p = q ? in[4 * q - 1] : prev;
+      const u32 d0 = v[0] - p, d1 = v[1] - v[0], d2 = v[2] - v[1], d3 = v[3] - v[2];
+      v[0] = d0; v[1] = d1; v[2] = d2; v[3] = d3;
+    }
+    if (ZZ) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = zz_enc(v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += len_of<V>(code_of<V>(v[k]));
+  }
+  // tail values (count % 4), handled by the first threads of block 0
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3u)) {
+    const u64 i = (nquads << 2) + threadIdx.x;
+    u32 v = in[i];
+    if (DELTA) v -= i ? in[i - 1] : prev;
+    if (ZZ) v = zz_enc(v);
+    acc += len_of<V>(code_of<V>(v));
+  }
+  const u64 tot = block_sum64(acc, s_tmp);
+  if (threadIdx.x == 0) {
+    const u64 add = tot + (blockIdx.x == 0 ? (((u64)count + 3) >> 2) : 0);
+    if (add) atomicAdd(reinterpret_cast<unsigned long long*>(result), (unsigned long long)add);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_validate_sum: data bytes promised by the first `count` codes of the key
+// block (reference src/streamvbyte_decode.c:113-133,
+// src/streamvbyte_0124_decode.c:206-226).  *accum must be zero before launch.
+// Reads 0.25 B per value.
+template <int V>
+__global__ __launch_bounds__(kBlock) void k_validate_sum(const u8* __restrict__ in, u32 count,
+                                                         u64* __restrict__ accum) {
+  __shared__ u64 s_tmp[kWaves];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u64 nchunks = (keylen + 15) >> 4;
+  u64 acc = 0;
+  for (u64 c = (u64)blockIdx.x * kBlock + threadIdx.x; c < nchunks; c += (u64)gridDim.x * kBlock) {
+    const u64 koff = c << 4;
+    uint4 k = make_uint4(0, 0, 0, 0);
+    if (koff + 16 <= keylen) {
+      k = ld_u128(in + koff);
+    } else {  // last chunk: stay inside the key block, validation may not trust what follows
+      u32 w[4] = {0, 0, 0, 0};
+      for (u64 b = koff; b < keylen; ++b) w[(b - koff) >> 2] |= (u32)in[b] << (8 * ((b - koff) & 3));
+      k = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    const u64 first = koff * 4;
+    const u32 nv = (u32)min((u64)64, (u64)count - first);
+    const u32 w[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
+      acc += word_len<V>(mask_codes(w[d], nvd), nvd);
+    }
+  }
+  const u64 tot = block_sum64(acc, s_tmp);
+  if (threadIdx.x == 0 && tot)
+    atomicAdd(reinterpret_cast<unsigned long long*>(accum), (unsigned long long)tot);
+}
+
+// Final comparison of streamvbyte_validate_stream (reference
+// src/streamvbyte_decode.c:91-102,135).
+__global__ void k_validate_finish(const u64* __restrict__ accum, u64 in_length, u32 count,
+                                  u32* __restrict__ ok) {
+  if (threadIdx.x || blockIdx.x) return;
+  u32 r;
+  if (in_length == 0 || count == 0) {
+    r = in_length == (u64)count;
+  } else {
+    const u64 keylen = ((u64)count + 3) >> 2;
+    r = keylen <= in_length && *accum == in_length - keylen;
+  }
+  *ok = r;
+}
+
+// ---------------------------------------------------------------------------
+// Zigzag maps (reference src/streamvbyte_zigzag.c:3-29).  8 B per value.
+// MODE 0: encode, 1: decode, 2: delta encode (out[i] = zz(in[i]-in[i-1])).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_zigzag(const u32* __restrict__ in,
+                                                   u32* __restrict__ out, u64 n, u32 prev) {
+  const u64 nquads = n >> 2;
+  for (u64 q = (u64)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (u64)gridDim.x * kBlock) {
+    uint4 x;
+    __builtin_memcpy(&x, in + 4 * q, 16);
+    uint4 y;
+    if (MODE == 0) {
+      y = make_uint4(zz_enc(x.x), zz_enc(x.y), zz_enc(x.z), zz_enc(x.w));
+    } else if (MODE == 1) {
+      y = make_uint4(zz_dec(x.x), zz_dec(x.y), zz_dec(x.z), zz_dec(x.w));
+    } else {
+      const u32 p = q ? in[4 * q - 1] : prev;
+      y = make_uint4(zz_enc(x.x - p), zz_enc(x.y - x.x), zz_enc(x.z - x.y), zz_enc(x.w - x.z));
+    }
+    __builtin_memcpy(out + 4 * q, &y, 16);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const u64 i = (nquads << 2) + threadIdx.x;
+    const u32 v = in[i];
+    u32 r;
+    if (MODE == 0) r = zz_enc(v);
+    else if (MODE == 1) r = zz_dec(v);
+    else r = zz_enc(v - (i ? in[i - 1] : prev));
+    out[i] = r;
+  }
+}
+
+}  // namespace svb

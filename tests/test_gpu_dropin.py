@@ -1,0 +1,148 @@
+"""The reference's own unit tests (tests/unit.c of lemire/streamvbyte) re-expressed
+against the drop-in host-pointer API of libstreamvbyte.so.2."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def svb():
+    import torch
+    assert torch.cuda.is_available()
+    import streamvbyte_amd
+    streamvbyte_amd.load()
+    return streamvbyte_amd
+
+
+def test_issue42(svb, golden):
+    """reference tests/unit.c:310-2783"""
+    arrays, _, stream = golden
+    out, used = svb.streamvbyte_decode(stream, 29159)
+    assert used == 36494
+    assert np.array_equal(out, arrays["issue42_decoded"])
+    again = svb.streamvbyte_encode(out)
+    assert again.size == 36494 and np.array_equal(again, stream)
+    out2, used2 = svb.streamvbyte_decode(again, 29159)
+    assert used2 == 36494 and np.array_equal(out2, out)
+
+
+def test_issue69(svb, golden):
+    """reference tests/unit.c:2786-2805"""
+    arrays, _, _ = golden
+    s = svb.streamvbyte_encode(arrays["issue69_values"])
+    assert np.array_equal(s, arrays["issue69_stream"])
+    out, used = svb.streamvbyte_decode(s, 22)
+    assert used == s.size and np.array_equal(out, arrays["issue69_values"])
+
+
+def test_zigzag(svb, golden):
+    """reference tests/unit.c:22-87"""
+    arrays, _, _ = golden
+    assert np.array_equal(svb.zigzag_encode(arrays["zigzag_fix_in"]), arrays["zigzag_fix_out"])
+    assert np.array_equal(svb.zigzag_decode(arrays["zigzag_fix_out"]), arrays["zigzag_fix_in"])
+    rng = np.random.default_rng(5)
+    d = (rng.integers(0, 2**31, 4096) - rng.integers(0, 2**31, 4096)).astype(np.int32)
+    assert np.array_equal(svb.zigzag_decode(svb.zigzag_encode(d)), d)
+    assert np.array_equal(svb.zigzag_delta_decode(svb.zigzag_delta_encode(d, 0), 0), d)
+
+
+def test_basictests(svb, oracle):
+    """reference tests/unit.c:90-185: lengths 0..128 then doubling to 4096,
+    gaps 3^k, misaligned compressed buffer, all three codecs."""
+    lib = svb.load()
+    rng = np.random.default_rng(11)
+    lengths = list(range(0, 129, 7)) + [127, 128, 256, 512, 1024, 2048, 4096]
+    N = 4096
+    raw = np.zeros(svb.streamvbyte_max_compressedbytes(N) + 3, dtype=np.uint8)
+    comp = raw[3:]  # misaligned on purpose (tests/unit.c:93-96)
+    for length in lengths:
+        gap = 1
+        while gap <= 387420489:
+            d = np.cumsum(gap - 1 + rng.integers(0, 8, size=max(length, 1)), dtype=np.uint64).astype(np.uint32)[:length]
+            recov = np.zeros(max(length, 1), dtype=np.uint32)
+            for enc, val, dec, variant in (
+                    (lib.streamvbyte_encode, lib.streamvbyte_validate_stream, lib.streamvbyte_decode, 0),
+                    (lib.streamvbyte_encode_0124, lib.streamvbyte_validate_stream_0124, lib.streamvbyte_decode_0124, 1)):
+                size = enc(d.ctypes.data, length, comp.ctypes.data)
+                assert size == oracle.compressedbytes(variant, d)
+                assert np.array_equal(comp[:size], oracle.encode(variant, d))
+                assert val(comp.ctypes.data, size, length)
+                used = dec(comp.ctypes.data, recov.ctypes.data, length)
+                assert used == size and np.array_equal(recov[:length], d)
+            gap *= 9
+        gap = 1
+        while gap <= 531441:
+            d = (gap * np.arange(length, dtype=np.uint64)).astype(np.uint32)
+            recov = np.zeros(max(length, 1), dtype=np.uint32)
+            size = lib.streamvbyte_delta_encode(d.ctypes.data, length, comp.ctypes.data, 0)
+            used = lib.streamvbyte_delta_decode(comp.ctypes.data, recov.ctypes.data, length, 0)
+            assert size == used and np.array_equal(recov[:length], d)
+            gap *= 9
+
+
+def test_aqrit_patterns(svb, oracle):
+    """reference tests/unit.c:187-252: every 0/1 pattern of 16 bytes as 4 ints
+    (as one long stream plus a sample of quads as length-4 streams)."""
+    bits = (np.arange(0x10000, dtype=np.uint32)[:, None] >> np.arange(16)) & 1
+    allv = bits.astype(np.uint8).view(np.uint32).reshape(-1)
+    for enc, dec, val, variant in (
+            (svb.streamvbyte_encode, svb.streamvbyte_decode, svb.streamvbyte_validate_stream, 0),
+            (svb.streamvbyte_encode_0124, svb.streamvbyte_decode_0124, svb.streamvbyte_validate_stream_0124, 1)):
+        s = enc(allv)
+        assert np.array_equal(s, oracle.encode(variant, allv))
+        assert val(s, allv.size)
+        out, used = dec(s, allv.size)
+        assert used == s.size and np.array_equal(out, allv)
+        for i in range(0, 0x10000, 1021):
+            q = allv[4 * i: 4 * i + 4]
+            s = enc(q)
+            assert np.array_equal(s, oracle.encode(variant, q))
+            out, used = dec(s, 4)
+            assert used == s.size and np.array_equal(out, q)
+
+
+def test_compressedbytes_known_answers(svb):
+    """reference tests/unit.c:254-308"""
+    for vals, a, b in (([1] * 4, 5, 5), ([260] * 4, 9, 9), ([2**32 - 1] * 4, 17, 17), ([0] * 4, 5, 1), ([], 0, 0)):
+        v = np.array(vals, dtype=np.uint32)
+        assert svb.streamvbyte_compressedbytes(v) == a
+        assert svb.streamvbyte_compressedbytes_0124(v) == b
+
+
+def test_perf_c_shape(svb, golden):
+    """reference tests/perf.c:52-53: glibc rand() data, known compressed size"""
+    _, scal, _ = golden
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    n = scal["perf_c"]["n"]
+    d = np.empty(n, dtype=np.uint32)
+    for k in range(n):
+        r = libc.rand()
+        s = libc.rand()
+        d[k] = r >> (31 & s)
+    if int(np.bitwise_xor.reduce(d)) != scal["perf_c"]["xor"]:
+        pytest.skip("libc rand() sequence differs from the one the fixture was made with")
+    s = svb.streamvbyte_encode(d)
+    assert s.size == scal["perf_c"]["bytes"]
+    out, used = svb.streamvbyte_decode(s, n)
+    assert used == s.size and np.array_equal(out, d)
+
+
+def test_device_pointers_through_reference_names(svb, oracle):
+    """The 14 reference symbols also accept hipMalloc'ed pointers."""
+    import torch
+    lib = svb.load()
+    rng = np.random.default_rng(3)
+    v = (rng.integers(0, 2**32, 50000, dtype=np.uint64) >> rng.integers(0, 32, 50000).astype(np.uint64)).astype(np.uint32)
+    expect = oracle.encode(0, v)
+    d_v = torch.from_numpy(v.view(np.int32)).cuda()
+    d_out = torch.zeros(svb.streamvbyte_max_compressedbytes(v.size), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    size = lib.streamvbyte_encode(d_v.data_ptr(), v.size, d_out.data_ptr())
+    assert size == expect.size and np.array_equal(d_out[:size].cpu().numpy(), expect)
+    d_back = torch.zeros_like(d_v)
+    used = lib.streamvbyte_decode(d_out.data_ptr(), d_back.data_ptr(), v.size)
+    assert used == size and np.array_equal(d_back.cpu().numpy().view(np.uint32), v)

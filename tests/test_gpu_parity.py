@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors.  Bit-exact for every byte and every integer."""
+import numpy as np
+import pytest
+
+from oracle import V1234, V0124
+from util import GENERATORS, dev_stream, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097,
+         16383, 16384, 16385, 65535, 65537, 100003, 262144 + 7, 1 << 20]
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def codec(torch_mod):
+    import streamvbyte_amd as svb
+    return svb.DeviceCodec(max_count=1 << 25)
+
+
+def gen(kind, n, seed):
+    return GENERATORS[kind](np.random.default_rng(seed), n)
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+@pytest.mark.parametrize("kind", ["width_mix", "sparse", "zeros", "max", "perf_c"])
+def test_decode_matches_oracle(torch_mod, codec, oracle, variant, kind):
+    for i, n in enumerate(SIZES):
+        v = gen(kind, n, 1000 + i)
+        s = oracle.encode(variant, v)
+        for misalign in ((0,) if i % 3 else (0, 3)):
+            d_in = dev_stream(torch_mod, s, misalign=misalign)
+            out, used = codec.decode(d_in, n, variant=variant)
+            assert int(used.item()) == s.size, (kind, n, misalign)
+            got = to_np(out, np.uint32)
+            assert np.array_equal(got, v), (kind, n, misalign, np.flatnonzero(got != v)[:5])
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+@pytest.mark.parametrize("kind", ["width_mix", "sparse", "zeros", "max", "perf_c"])
+def test_encode_matches_oracle(torch_mod, codec, oracle, variant, kind):
+    for i, n in enumerate(SIZES):
+        v = gen(kind, n, 2000 + i)
+        expect = oracle.encode(variant, v)
+        d_v = to_dev(torch_mod, v)
+        buf = torch_mod.full((3 + expect.size + 64 + 4 * n // 2 + 16,), 0xAB, dtype=torch_mod.uint8, device="cuda:0")
+        import streamvbyte_amd as svb
+        buf = torch_mod.full((3 + svb.streamvbyte_max_compressedbytes(n),), 0xAB, dtype=torch_mod.uint8, device="cuda:0")
+        mis = 3 if i % 2 else 0
+        out, size = codec.encode(d_v, out=buf[mis:], variant=variant)
+        codec.check()
+        assert int(size.item()) == expect.size, (kind, n)
+        got = buf[mis: mis + expect.size].cpu().numpy()
+        assert np.array_equal(got, expect), (kind, n, np.flatnonzero(got != expect)[:5])
+        if mis:
+            assert (buf[:mis].cpu().numpy() == 0xAB).all()  # nothing written in front of out
+
+
+@pytest.mark.parametrize("kind", ["postings", "full", "width_mix"])
+def test_delta_matches_oracle(torch_mod, codec, oracle, kind):
+    from streamvbyte_amd import DELTA
+    for i, n in enumerate(SIZES):
+        v = gen(kind, n, 3000 + i)
+        prev = [0, 7, 0xDEADBEEF][i % 3]
+        s = oracle.encode(V1234, v, True, prev)
+        out, size = codec.encode(to_dev(torch_mod, v), variant=V1234, flags=DELTA, prev=prev)
+        codec.check()
+        assert int(size.item()) == s.size
+        assert np.array_equal(out[: s.size].cpu().numpy(), s), (kind, n)
+        dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA, prev=prev)
+        codec.check()
+        assert int(used.item()) == s.size
+        assert np.array_equal(to_np(dec, np.uint32), v), (kind, n)
+
+
+def test_zigzag_fused_and_plain(torch_mod, codec, oracle):
+    from streamvbyte_amd import ZIGZAG, DELTA
+    for i, n in enumerate(SIZES):
+        g = gen("sparse", n, 4000 + i).view(np.int32)
+        d_g = to_dev(torch_mod, g)
+        zz = oracle.zigzag_encode(g)
+        assert np.array_equal(to_np(codec.zigzag(d_g, "encode"), np.uint32), zz)
+        assert np.array_equal(to_np(codec.zigzag(to_dev(torch_mod, zz), "decode"), np.int32), g)
+        prev = [0, -5, 2**31 - 1][i % 3]
+        zzd = oracle.zigzag_delta_encode(g, prev)
+        assert np.array_equal(to_np(codec.zigzag(d_g, "delta_encode", prev), np.uint32), zzd)
+        back = codec.zigzag(to_dev(torch_mod, zzd), "delta_decode", prev)
+        codec.check()
+        assert np.array_equal(to_np(back, np.int32), g)
+        # fused: zigzag inside the 0124 codec pass == zigzag_encode then encode_0124
+        expect = oracle.encode(V0124, zz)
+        out, size = codec.encode(d_g, variant=V0124, flags=ZIGZAG)
+        assert int(size.item()) == expect.size
+        assert np.array_equal(out[: expect.size].cpu().numpy(), expect)
+        dec, used = codec.decode(dev_stream(torch_mod, expect), n, variant=V0124, flags=ZIGZAG)
+        assert int(used.item()) == expect.size
+        assert np.array_equal(to_np(dec, np.int32), g)
+        # fused signed delta: zigzag_delta_encode then encode
+        expect = oracle.encode(V1234, zzd)
+        out, size = codec.encode(d_g, variant=V1234, flags=ZIGZAG | DELTA, prev=prev)
+        codec.check()
+        assert int(size.item()) == expect.size
+        assert np.array_equal(out[: expect.size].cpu().numpy(), expect)
+        dec, used = codec.decode(dev_stream(torch_mod, expect), n, variant=V1234, flags=ZIGZAG | DELTA, prev=prev)
+        codec.check()
+        assert np.array_equal(to_np(dec, np.int32), g)
+
+
+def test_size_and_validate(torch_mod, codec, oracle):
+    for i, n in enumerate(SIZES):
+        v = gen("perf_c", n, 5000 + i)
+        d_v = to_dev(torch_mod, v)
+        for variant in (V1234, V0124):
+            s = oracle.encode(variant, v)
+            assert int(codec.compressedbytes(d_v, variant=variant).item()) == s.size
+            d_s = dev_stream(torch_mod, s)
+            for inlen, cnt in ((s.size, n), (s.size + 1, n), (s.size - 1, n), (s.size, n + 1), (s.size, n - 1),
+                               (0, n), (s.size, 0), (0, 0), ((n + 3) // 4 - 1, n)):
+                if inlen < 0 or cnt < 0:
+                    continue
+                expect = oracle.validate(variant, s, cnt, inlen) if (cnt + 3) // 4 <= s.size + 16 else False
+                got = bool(codec.validate(d_s, inlen, cnt, variant=variant).item() & 0xFFFFFFFF)
+                assert got == expect, (n, variant, inlen, cnt)
+
+
+def test_golden_vectors(torch_mod, codec, golden):
+    """issue42 / issue69 / README vector (reference tests/unit.c:310-2805, README.md:228-242)
+    and the reference-generated seeded cases, straight from tests/golden/."""
+    from streamvbyte_amd import DELTA
+    arrays, scal, issue42 = golden
+    out, used = codec.decode(dev_stream(torch_mod, issue42), 29159)
+    assert int(used.item()) == 36494
+    assert np.array_equal(to_np(out, np.uint32), arrays["issue42_decoded"])
+    enc, size = codec.encode(out)
+    codec.check()
+    assert int(size.item()) == 36494 and np.array_equal(enc[:36494].cpu().numpy(), issue42)
+    for vals, stream in ((arrays["issue69_values"], arrays["issue69_stream"]),
+                         (arrays["readme_values"], arrays["readme_stream"])):
+        enc, size = codec.encode(to_dev(torch_mod, vals))
+        assert np.array_equal(enc[: int(size.item())].cpu().numpy(), stream)
+    for c in scal["cases"]:
+        i, n, prev = c["id"], c["n"], c["prev"]
+        if n == 0:
+            continue
+        v = arrays[f"case{i}_values"]
+        d_v = to_dev(torch_mod, v)
+        for variant, key, flags, p in ((V1234, "s1234", 0, 0), (V0124, "s0124", 0, 0), (V1234, "sdelta", DELTA, prev)):
+            s = arrays[f"case{i}_{key}"]
+            enc, size = codec.encode(d_v, variant=variant, flags=flags, prev=p)
+            codec.check()
+            assert int(size.item()) == s.size and np.array_equal(enc[: s.size].cpu().numpy(), s), (i, key)
+            dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=variant, flags=flags, prev=p)
+            codec.check()
+            assert int(used.item()) == s.size and np.array_equal(to_np(dec, np.uint32), v), (i, key)
+
+
+def test_batched_streams(torch_mod, codec, oracle):
+    from streamvbyte_amd import DELTA, streamvbyte_max_compressedbytes
+    torch = torch_mod
+    rng = np.random.default_rng(99)
+    ns = 3000
+    counts = np.floor(np.exp(rng.uniform(0, np.log(4096), size=ns))).astype(np.uint32)
+    counts[:8] = [0, 1, 3, 4, 5, 1024, 1025, 5000]
+    prevs = rng.integers(0, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)
+    voff = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    cap = np.array([streamvbyte_max_compressedbytes(int(c)) for c in counts], dtype=np.uint64)
+    boff = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+    values = np.concatenate([np.cumsum(rng.integers(0, 300, size=int(c)), dtype=np.uint64).astype(np.uint32)
+                             if k % 2 else GENERATORS["perf_c"](rng, int(c)) for k, c in enumerate(counts)])
+    d_values = to_dev(torch, values)
+    d_voff = torch.from_numpy(voff[:-1].astype(np.int64)).cuda()
+    d_boff = torch.from_numpy(boff[:-1].astype(np.int64)).cuda()
+    d_counts = to_dev(torch, counts)
+    d_prevs = to_dev(torch, prevs)
+    for variant, flags in ((V1234, 0), (V0124, 0), (V1234, DELTA)):
+        buf = torch.zeros(int(boff[-1]) + 16, dtype=torch.uint8, device="cuda:0")
+        sizes = codec.encode_batch(d_values, d_voff, buf, d_boff, d_counts, d_prevs, variant=variant, flags=flags)
+        h_sizes = sizes.cpu().numpy()
+        h_buf = buf.cpu().numpy()
+        for s in range(ns):
+            v = values[int(voff[s]): int(voff[s + 1])]
+            expect = oracle.encode(variant, v, bool(flags & DELTA), int(prevs[s]))
+            assert h_sizes[s] == expect.size, (s, counts[s])
+            assert np.array_equal(h_buf[int(boff[s]): int(boff[s]) + expect.size], expect), (s, counts[s])
+        back = torch.zeros_like(d_values)
+        used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+        assert np.array_equal(used.cpu().numpy(), h_sizes)
+        assert np.array_equal(to_np(back, np.uint32), values)
