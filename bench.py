@@ -1,0 +1,386 @@
+#!/usr/bin/env python3
+"""StreamVByte on MI355X: device-resident decode / encode throughput.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 28] [--quick]
+
+Workload (every rank): one stream of 2^28 uint32 whose byte widths are uniform
+over {1,2,3,4} (value uniform inside its width class), seed fixed per rank.
+The stream is encoded on the GPU, checked, and then decoded K times in the
+timed region: one step = one full streamvbyte_decode of the stream through the
+C ABI (svbgpu_decode_plan + svbgpu_decode_run, i.e. every kernel of the
+decode path).  `value` = 4*n*K*ranks / time in GB/s on the uint32 output.
+With N > 1 every rank decodes its own independent stream (streams are the
+sharding unit, nothing is exchanged on the data path); the batched posting-list
+workload with its RCCL all-gather of sizes is reported under "batched".
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=28)
+    ap.add_argument("--quick", action="store_true", help="skip the secondary workloads and the CPU baseline")
+    ap.add_argument("--lists", type=int, default=1 << 20, help="posting lists in the batched workload (whole job)")
+    return ap.parse_args()
+
+
+def gen_width_mix(torch, n, seed, device):
+    """uint32 with byte width uniform over {1,2,3,4}; returns an int32 tensor holding the bits."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    chunk = 1 << 26
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        w = torch.randint(1, 5, (m,), generator=g, device=device, dtype=torch.int64)
+        lo = torch.where(w == 1, torch.zeros_like(w), torch.ones_like(w) << (8 * (w - 1)))
+        hi = torch.ones_like(w) << (8 * w)
+        r = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+        v = lo + (r * (hi - lo).to(torch.float64)).to(torch.int64)
+        v = torch.minimum(v, hi - 1)
+        out[s:s + m] = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)
+        del w, lo, hi, r, v
+    return out
+
+
+def time_steps(torch, fn, steps, warmup, dist=None):
+    """barrier + sync, K steps, sync + barrier; returns seconds (max over ranks)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return t1 - t0
+
+
+def event_ms(torch, fn, iters, warmup=2):
+    """mean milliseconds of fn() measured with HIP events on the current stream"""
+    for _ in range(warmup):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    return float(np.mean(ms)), float(ms[len(ms) // 2])
+
+
+def cpu_baseline(values_host, threads_all):
+    """The reference library (or, where it was not built, the oracle port) on the
+    host cores: decode of a bounded sample, one thread and all threads."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle, Reference, max_compressedbytes
+    try:
+        cpu = Reference()
+    except FileNotFoundError:
+        cpu = Oracle()
+    n = values_host.size
+    u8p, u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)
+
+    def enc(v, out):
+        return cpu._encode(0, v, v.size, out, False, 0)
+
+    def dec(s, out, m):
+        return cpu._decode(0, s, out, m, False, 0)
+
+    comp = np.zeros(max_compressedbytes(n), dtype=np.uint8)
+    size = enc(values_host, comp)
+    back = np.empty(n, dtype=np.uint32)
+    dec(comp, back, n)
+    assert np.array_equal(back, values_host)
+
+    def best_of(f, reps):
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    reps = 5
+    t_dec = best_of(lambda: dec(comp, back, n), reps)
+    t_enc = best_of(lambda: enc(values_host, comp), reps)
+
+    # all cores: P equal independent streams, one thread each (ctypes drops the GIL)
+    P = threads_all
+    per = n // P
+    parts = [np.ascontiguousarray(values_host[i * per:(i + 1) * per]) for i in range(P)]
+    comps = [np.zeros(max_compressedbytes(per), dtype=np.uint8) for _ in range(P)]
+    outs = [np.empty(per, dtype=np.uint32) for _ in range(P)]
+    for i in range(P):
+        enc(parts[i], comps[i])
+
+    def run_all(job):
+        ths = [threading.Thread(target=job, args=(i,)) for i in range(P)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    t_dec_all = best_of(lambda: run_all(lambda i: dec(comps[i], outs[i], per)), 3)
+    t_enc_all = best_of(lambda: run_all(lambda i: enc(parts[i], comps[i])), 3)
+    gb = 4.0 * n / 1e9
+    return {
+        "value": round(gb / t_dec, 3), "unit": "GB/s (uint32 out, decode)", "cores": 1, "kind": cpu.kind,
+        "sample": f"first 2^{int(np.log2(n))} values of the workload, best of {reps}, DRAM-resident "
+                  f"({size} B stream)",
+        "decode_Gints_per_s": round(n / t_dec / 1e9, 3),
+        "encode_GBps": round(gb / t_enc, 3),
+        "all_cores": {"cores": P, "decode_GBps": round(4.0 * per * P / 1e9 / t_dec_all, 3),
+                      "encode_GBps": round(4.0 * per * P / 1e9 / t_enc_all, 3),
+                      "note": f"{P} equal independent streams, one thread each"},
+    }
+
+
+def gen_posting_lists(torch, nlists, seed, device):
+    """lengths log-uniform on [1,4096]; sorted lists with small gaps (1-2 byte deltas)"""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u = torch.rand(nlists, generator=g, device=device, dtype=torch.float64)
+    counts = torch.exp(u * np.log(4096.0)).floor().clamp_(1, 4096).to(torch.int64)
+    voff = torch.zeros(nlists + 1, dtype=torch.int64, device=device)
+    voff[1:] = torch.cumsum(counts, 0)
+    total = int(voff[-1].item())
+    gaps = torch.randint(0, 1 << 12, (total,), generator=g, device=device, dtype=torch.int64)
+    small = torch.rand(total, generator=g, device=device) < 0.7
+    gaps = torch.where(small, gaps & 0xFF, gaps)
+    cs = torch.cumsum(gaps, 0)
+    # restart the running sum at every list start
+    starts = voff[:-1]
+    first = cs[starts] - gaps[starts]
+    vals = cs - torch.repeat_interleave(first, counts)
+    del cs, gaps, small
+    vals32 = torch.where(vals >= (1 << 31), vals - (1 << 32), vals).to(torch.int32)
+    return counts.to(torch.int32), voff, vals32
+
+
+def main():
+    a = parse()
+    import torch
+    import streamvbyte_amd as svb
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist = dist_mod
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    n = 1 << a.log2n
+    codec = svb.DeviceCodec(n, device)
+
+    # ---- workload ------------------------------------------------------------
+    values = gen_width_mix(torch, n, 0x5356425F43320001 + rank, device)
+    stream, size_t = codec.encode(values)
+    codec.check()
+    size = int(size_t.item())
+    keylen = (n + 3) // 4
+    dbar = (size - keylen) / n
+    out = torch.empty(n, dtype=torch.int32, device=device)
+
+    # parity outside the timed region: round trip, sizes, validate, oracle on a slice
+    dec, used = codec.decode(stream, n, out=out)
+    parity = bool(torch.equal(dec, values)) and int(used.item()) == size
+    parity &= int(codec.compressedbytes(values).item()) == size
+    parity &= bool(int(codec.validate(stream, size, n).item()) & 1)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle
+    m = min(n, 1 << 22)
+    sl = values[:m].cpu().numpy().view(np.uint32)
+    ref_stream = Oracle().encode(0, sl)
+    got, got_size = codec.encode(values[:m].contiguous())
+    parity &= int(got_size.item()) == ref_stream.size and bool(
+        np.array_equal(got[: ref_stream.size].cpu().numpy(), ref_stream))
+    codec.check()
+
+    # ---- timed region: K full decodes ---------------------------------------
+    ev = {"plan": [], "run": []}
+
+    def step():
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        codec.decode_plan(stream, n)
+        e1.record()
+        codec.decode_run(stream, n, out)
+        e2.record()
+        ev["plan"].append((e0, e1))
+        ev["run"].append((e1, e2))
+
+    def step_warm():
+        codec.decode_plan(stream, n)
+        codec.decode_run(stream, n, out)
+
+    for _ in range(a.warmup):
+        step_warm()
+    t = time_steps(torch, step, a.steps, 0, dist)
+    run_ms = float(np.mean([x.elapsed_time(y) for x, y in ev["run"]]))
+    plan_ms = float(np.mean([x.elapsed_time(y) for x, y in ev["plan"]]))
+    value = 4.0 * n * a.steps * world / t / 1e9
+    alg_bytes = (4.25 + dbar) * n  # keys 0.25 + data dbar + output 4 bytes per value
+    achieved = alg_bytes / (run_ms * 1e-3) / 1e9
+
+    res = {
+        "metric": "device-resident decode GB/s (uint32 out)",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"single 2^{a.log2n}-integer stream per GPU, byte widths uniform over 1-4, "
+                               "streamvbyte_decode (1234), bit-exact",
+                   "values_per_stream": n, "stream_bytes": size, "data_bytes_per_value": round(dbar, 4),
+                   "streams": world, "parallelism": f"one independent stream per GPU x{world}"},
+        "decode_Gints_per_s": round(n * a.steps * world / t / 1e9, 2),
+        "parity": "bit-exact" if parity else "MISMATCH",
+        "roofline": {"bound": "hbm", "kernel": "k_decode<1234>", "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "kernel_ms": round(run_ms, 4), "directory_ms": round(plan_ms, 4),
+                     "whole_step_frac": round((alg_bytes + 0.25 * n) / (t / a.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+    # ---- encode, same stream --------------------------------------------------
+    enc_out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device=device)
+    te = time_steps(torch, lambda: codec.encode(values, out=enc_out), max(3, a.steps // 2), 2, dist)
+    codec.check()
+    ke = max(3, a.steps // 2)
+    res["encode"] = {"value": round(4.0 * n * ke * world / te / 1e9, 2), "unit": "GB/s (uint32 in)",
+                     "Gints_per_s": round(n * ke * world / te / 1e9, 2), "ms": round(te / ke * 1e3, 4),
+                     "roofline_frac": round(alg_bytes / (te / ke) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    if not a.quick:
+        extra = {}
+        it = 5
+        # C3 dense postings: gaps U[0,31], all 1-byte deltas, prev = 0
+        g = torch.Generator(device=device)
+        g.manual_seed(7 + rank)
+        n3 = n
+        post = torch.cumsum(torch.randint(0, 32, (n3,), generator=g, device=device, dtype=torch.int64), 0)
+        post = torch.where(post >= (1 << 31), post - (1 << 32), post).to(torch.int32)
+        s3, z3 = codec.encode(post, variant=svb.V1234, flags=svb.DELTA, prev=0)
+        sz3 = int(z3.item())
+        d3 = (sz3 - keylen) / n3
+        ms_e, _ = event_ms(torch, lambda: codec.encode(post, out=enc_out, variant=svb.V1234, flags=svb.DELTA), it)
+        ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3, out=out, flags=svb.DELTA), it)
+        codec.check()
+        ok3 = bool(torch.equal(out, post))
+        extra["delta_postings"] = {"n": n3, "data_bytes_per_value": round(d3, 4), "parity": ok3,
+                                   "decode_GBps": round(4.0 * n3 / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n3 / ms_e / 1e6, 1),
+                                   "decode_roofline_frac": round((4.25 + d3) * n3 / ms_d / 1e6 / HBM_PEAK_GBS, 4),
+                                   "encode_roofline_frac": round((4.25 + d3) * n3 / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
+        del post, s3
+        # C4 gradients: int32 ~ round(N(0,0.8)) with 0.1% outliers, zigzag fused into the 0124 codec
+        n4 = min(n, 1 << 26)
+        gr = torch.round(torch.randn(n4, generator=g, device=device) * 0.8).to(torch.int32)
+        outl = torch.rand(n4, generator=g, device=device) < 0.001
+        gr = torch.where(outl, torch.randint(-(1 << 20), 1 << 20, (n4,), generator=g, device=device, dtype=torch.int32), gr)
+        s4, z4 = codec.encode(gr, variant=svb.V0124, flags=svb.ZIGZAG)
+        sz4 = int(z4.item())
+        d4 = (sz4 - (n4 + 3) // 4) / n4
+        o4 = out[:n4]
+        ms_e, _ = event_ms(torch, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG), it)
+        ms_d, _ = event_ms(torch, lambda: codec.decode(s4, n4, out=o4, variant=svb.V0124, flags=svb.ZIGZAG), it)
+        ok4 = bool(torch.equal(o4, gr))
+        tmp = torch.empty(n4, dtype=torch.int32, device=device)
+        ms_uf, _ = event_ms(torch, lambda: (codec.decode(s4, n4, out=tmp, variant=svb.V0124),
+                                            codec.zigzag(tmp, "decode", out=o4)), it)
+        extra["zigzag_0124_gradients"] = {"n": n4, "data_bytes_per_value": round(d4, 4), "parity": ok4,
+                                          "decode_GBps": round(4.0 * n4 / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n4 / ms_e / 1e6, 1),
+                                          "decode_unfused_GBps": round(4.0 * n4 / ms_uf / 1e6, 1),
+                                          "decode_roofline_frac": round((4.25 + d4) * n4 / ms_d / 1e6 / HBM_PEAK_GBS, 4),
+                                          "encode_roofline_frac": round((4.25 + d4) * n4 / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
+        del gr, s4, tmp
+        # validate (0.25 B/value) and exact size (4 B/value) on the main stream
+        ms_v, _ = event_ms(torch, lambda: codec.validate(stream, size, n), it)
+        ms_s, _ = event_ms(torch, lambda: codec.compressedbytes(values), it)
+        extra["validate_stream"] = {"ms": round(ms_v, 4), "roofline_frac": round(0.25 * n / ms_v / 1e6 / HBM_PEAK_GBS, 4)}
+        extra["compressedbytes"] = {"ms": round(ms_s, 4), "roofline_frac": round(4.0 * n / ms_s / 1e6 / HBM_PEAK_GBS, 4)}
+        res["extra"] = extra
+
+        # ---- batched posting lists, sharded over ranks ----------------------------
+        nl = a.lists // world
+        counts, voff, vals = gen_posting_lists(torch, nl, 1234 + rank, device)
+        tot = int(voff[-1].item())
+        cap = (counts.to(torch.int64) + 3) // 4 + 4 * counts.to(torch.int64) + 16
+        boff = torch.zeros(nl + 1, dtype=torch.int64, device=device)
+        boff[1:] = torch.cumsum(cap, 0)
+        bbuf = torch.empty(int(boff[-1].item()) + 16, dtype=torch.uint8, device=device)
+        back = torch.empty_like(vals)
+        sizes = torch.empty(nl, dtype=torch.int64, device=device)
+        gathered = [torch.empty(nl, dtype=torch.int64, device=device) for _ in range(world)] if dist else None
+
+        def enc_batch():
+            codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=svb.DELTA, sizes=sizes)
+            if dist:
+                dist.all_gather(gathered, sizes)  # per-stream sizes -> global directory (RCCL)
+
+        def dec_batch():
+            codec.decode_batch(bbuf, boff[:-1], back, voff[:-1], counts, None, flags=svb.DELTA)
+
+        kb = 5
+        tb_e = time_steps(torch, enc_batch, kb, 1, dist)
+        tb_d = time_steps(torch, dec_batch, kb, 1, dist)
+        okb = bool(torch.equal(back, vals))
+        tot_t = torch.tensor([tot], dtype=torch.int64, device=device)
+        if dist:
+            dist.all_reduce(tot_t)
+        tot_all = int(tot_t.item())
+        dB = float((sizes.sum().item() - ((counts.to(torch.int64) + 3) // 4).sum().item()) / tot)
+        res["batched"] = {"workload": f"{nl * world} posting lists (log-uniform 1..4096 values), delta coded, "
+                                      f"sharded {nl} per GPU, RCCL all-gather of sizes" + ("" if dist else " (1 rank: no collective)"),
+                          "values": tot_all, "data_bytes_per_value": round(dB, 4), "parity": okb,
+                          "decode_GBps": round(4.0 * tot_all * kb / tb_d / 1e9, 1),
+                          "encode_GBps": round(4.0 * tot_all * kb / tb_e / 1e9, 1),
+                          "decode_roofline_frac": round((4.25 + dB) * tot_all * kb / tb_d / 1e9 / HBM_PEAK_GBS / world, 4),
+                          "encode_roofline_frac": round((4.25 + dB) * tot_all * kb / tb_e / 1e9 / HBM_PEAK_GBS / world, 4)}
+        del vals, back, bbuf
+
+        if rank == 0 and world == 1:
+            m = min(n, 1 << 26)
+            host = values[:m].cpu().numpy().view(np.uint32).copy()
+            res["cpu_baseline"] = cpu_baseline(host, min(16, os.cpu_count() or 1))
+
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    return 0 if parity else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

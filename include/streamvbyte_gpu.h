@@ -65,6 +65,17 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t *d_in, uint32_t *d_
                   uint32_t count, uint32_t prev, void *d_workspace, size_t workspace_bytes,
                   uint64_t *d_consumed, void *stream);
 
+/* The two halves of svbgpu_decode, for callers that decode one stream more
+ * than once (cached posting lists) or want the phases on different streams:
+ * _plan reads only the control bytes and leaves the data-offset directory of
+ * the stream in the workspace; _run decodes with that directory.  The
+ * workspace must not be used by another call in between. */
+int svbgpu_decode_plan(int variant, const uint8_t *d_in, uint32_t count, void *d_workspace,
+                       size_t workspace_bytes, void *stream);
+int svbgpu_decode_run(int variant, unsigned flags, const uint8_t *d_in, uint32_t *d_out,
+                      uint32_t count, uint32_t prev, void *d_workspace, size_t workspace_bytes,
+                      uint64_t *d_consumed, void *stream);
+
 /* Device-pointer form of streamvbyte_encode / _encode_0124 /
  * streamvbyte_delta_encode (reference include/streamvbyte.h:23,27,
  * include/streamvbytedelta.h:19).  d_written (optional) receives the bytes

@@ -187,6 +187,18 @@ class DeviceCodec:
                    "svbgpu_decode")
         return out, self.res[1:2]
 
+    def decode_plan(self, stream, count, variant=V1234):
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode_plan(variant, stream.data_ptr(), count, self.ws.data_ptr(),
+                                               self.ws_bytes, self._stream()), "svbgpu_decode_plan")
+
+    def decode_run(self, stream, count, out, variant=V1234, flags=0, prev=0):
+        with self.torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode_run(variant, flags, stream.data_ptr(), out.data_ptr(), count,
+                                              prev & 0xFFFFFFFF, self.ws.data_ptr(), self.ws_bytes,
+                                              self._res_ptr(1), self._stream()), "svbgpu_decode_run")
+        return out, self.res[1:2]
+
     def compressedbytes(self, values, variant=V1234, flags=0, prev=0):
         with self.torch.cuda.device(self.device):
             _check(self.lib.svbgpu_compressedbytes(variant, flags, values.data_ptr(), values.numel(),

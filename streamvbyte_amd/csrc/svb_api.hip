@@ -224,6 +224,32 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
   return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
 }
 
+int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* ws, size_t ws_bytes,
+                       void* stream) {
+  if (bad_variant(variant)) return SVBGPU_EINVAL;
+  if (count == 0) return SVBGPU_OK;
+  if (!d_in) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  return build_directory(variant, d_in, count, ws, S(stream));
+}
+
+int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out,
+                      uint32_t count, uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed,
+                      void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (count == 0) {
+    if (d_consumed) HIP_TRY(hipMemsetAsync(d_consumed, 0, 8, S(stream)));
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+}
+
 int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,
                   uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_written, void* stream) {
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
