@@ -99,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_scan_super(const u32* __restrict__ sup
 // Per-wave LDS: 256 entries (data offset | key<<16) + the wave tile's data span.
 struct __align__(16) WaveLds {
   u32 ent[kWtKeys];
-  u8 data[kWtDataMax + 48];  // +16 alignment slack, +16 partial chunk, +slack for 4-byte over-read
+  u8 data[kWtDataMax + 48];  // +16 alignment slack, +16 partial chunk, +slack for 8-byte over-read
 };
 
 // Blocked phase: lane holds keys 4l..4l+3 in w.  Writes the 4 entries of those
@@ -155,7 +155,11 @@ __device__ __forceinline__ uint4 extract_group(u32 entry, u32 shift, const u8* s
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const u32 c = (key >> (2 * k)) & 3u;
+#ifdef SVB_UNALIGNED_LDS
     v[k] = lds_u32(sdata + p) & mask_of<V>(c);
+#else
+    v[k] = lds_u32_aligned(sdata, p) & mask_of<V>(c);
+#endif
     p += len_of<V>(c);
   }
   return make_uint4(v[0], v[1], v[2], v[3]);

@@ -50,6 +50,14 @@ __device__ __forceinline__ u32 lds_u32(const u8* p) {
   __builtin_memcpy(&v, p, 4);
   return v;
 }
+// The 4 bytes at byte offset `p` of an LDS image, read as the aligned dword
+// pair that holds them and funnel-shifted (a misaligned ds_read_b32 is legal on
+// gfx950 but is replayed lane by lane).
+__device__ __forceinline__ u32 lds_u32_aligned(const u8* base, u32 p) {
+  const u32* q = reinterpret_cast<const u32*>(base + (p & ~3u));
+  const u32 lo = q[0], hi = q[1];
+  return __builtin_amdgcn_alignbyte(hi, lo, p);
+}
 
 // Inclusive prefix sum over the 64 lanes of a wavefront.
 __device__ __forceinline__ u32 wave_scan_incl(u32 x, int lane) {

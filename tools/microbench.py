@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Kernel-level timings with HIP events (one process, interleaved rounds).
+
+    python tools/microbench.py [--log2n 28] [--rounds 5] [--only decode,encode,...]
+Prints one line per operation: median ms, algorithmic GB/s and fraction of 8 TB/s.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import streamvbyte_amd as svb  # noqa: E402
+from bench import gen_width_mix, gen_posting_lists  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log2n", type=int, default=28)
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--only", default="")
+a = ap.parse_args()
+only = set(a.only.split(",")) if a.only else None
+n = 1 << a.log2n
+dev = "cuda:0"
+codec = svb.DeviceCodec(n, dev)
+ops = {}
+
+
+def want(name):
+    return only is None or name in only
+
+
+values = gen_width_mix(torch, n, 1, dev)
+stream, sz = codec.encode(values)
+size = int(sz.item())
+keylen = (n + 3) // 4
+dbar = (size - keylen) / n
+out = torch.empty(n, dtype=torch.int32, device=dev)
+enc_out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device=dev)
+if want("decode"):
+    ops["decode_plan"] = (lambda: codec.decode_plan(stream, n), 0.25 * n)
+    ops["decode_run"] = (lambda: codec.decode_run(stream, n, out), (4.25 + dbar) * n)
+if want("encode"):
+    ops["encode"] = (lambda: codec.encode(values, out=enc_out), (4.25 + dbar) * n)
+if want("delta"):
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    post = torch.cumsum(torch.randint(0, 32, (n,), generator=g, device=dev, dtype=torch.int64), 0)
+    post = torch.where(post >= (1 << 31), post - (1 << 32), post).to(torch.int32)
+    s3, z3 = codec.encode(post, flags=svb.DELTA)
+    s3 = s3.clone()
+    d3 = (int(z3.item()) - keylen) / n
+    ops["delta_encode"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
+    ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
+if want("zz"):
+    n4 = min(n, 1 << 26)
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    gr = torch.round(torch.randn(n4, generator=g, device=dev) * 0.8).to(torch.int32)
+    s4, z4 = codec.encode(gr, variant=svb.V0124, flags=svb.ZIGZAG)
+    s4 = s4.clone()
+    d4 = (int(z4.item()) - (n4 + 3) // 4) / n4
+    o4 = out[:n4]
+    ops["zz0124_encode"] = (lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
+    ops["zz0124_decode"] = (lambda: codec.decode(s4, n4, out=o4, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
+if want("misc"):
+    ops["validate"] = (lambda: codec.validate(stream, size, n), 0.25 * n)
+    ops["size"] = (lambda: codec.compressedbytes(values), 4.0 * n)
+    ops["zigzag_enc"] = (lambda: codec.zigzag(values, "encode", out=out), 8.0 * n)
+    tmpz = torch.empty(n, dtype=torch.int32, device=dev)
+    ops["zigzag_delta_dec"] = (lambda: codec.zigzag(values, "delta_decode", out=tmpz), 8.0 * n)
+if want("batch"):
+    nl = 1 << 20
+    counts, voff, vals = gen_posting_lists(torch, nl, 1234, dev)
+    tot = int(voff[-1].item())
+    cap = (counts.to(torch.int64) + 3) // 4 + 4 * counts.to(torch.int64) + 16
+    boff = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
+    boff[1:] = torch.cumsum(cap, 0)
+    bbuf = torch.empty(int(boff[-1].item()) + 16, dtype=torch.uint8, device=dev)
+    back = torch.empty_like(vals)
+    sizes = codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=svb.DELTA)
+    dB = float((sizes.sum().item() - ((counts.to(torch.int64) + 3) // 4).sum().item()) / tot)
+    ops["batch_encode"] = (lambda: codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=svb.DELTA, sizes=sizes), (4.25 + dB) * tot)
+    ops["batch_decode"] = (lambda: codec.decode_batch(bbuf, boff[:-1], back, voff[:-1], counts, None, flags=svb.DELTA, sizes=sizes), (4.25 + dB) * tot)
+
+for f, _ in ops.values():
+    f()
+torch.cuda.synchronize()
+times = {k: [] for k in ops}
+for r in range(a.rounds):
+    for k, (f, _) in ops.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record()
+        torch.cuda.synchronize()
+        times[k].append(e0.elapsed_time(e1))
+codec.check()
+print(f"n=2^{a.log2n} dbar={dbar:.3f}")
+for k, (f, nbytes) in ops.items():
+    ms = float(np.median(times[k]))
+    print(f"{k:18s} {ms:8.4f} ms  min {min(times[k]):8.4f}  {nbytes / ms / 1e6:8.1f} GB/s alg  {nbytes / ms / 1e6 / 8000:6.3f} of 8TB/s")
