@@ -47,6 +47,12 @@ const char *svbgpu_strerror(int code);
 /* 1 when the current HIP device is a gfx950 the library can run on. */
 int svbgpu_device_ok(void);
 
+/* Tuning knobs (process-wide, not thread-safe against running calls):
+ *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
+ *                               encoder carries through the look-back (default 4)
+ * Results never depend on a knob, only speed. */
+int svbgpu_set_option(const char *name, int value);
+
 /* Device scratch any single-stream call below needs for `count` values.
  * The workspace must be 256-byte aligned; its contents are undefined between
  * calls, and two calls that share a workspace must be ordered on one stream. */

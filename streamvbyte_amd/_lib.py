@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstreamvbyte.so.2")
+LIB_PATH = os.environ.get("SVB_LIB_PATH") or os.path.join(HERE, "libstreamvbyte.so.2")
 
 u8p, u32p, i32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_int32, C.c_uint64))
 vp = C.c_void_p
@@ -31,6 +31,7 @@ SIGNATURES = {
     "svbgpu_strerror": (C.c_char_p, [C.c_int]),
     "svbgpu_device_ok": (C.c_int, []),
     "svbgpu_workspace_bytes": (C.c_size_t, [C.c_uint32]),
+    "svbgpu_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "svbgpu_check_status": (C.c_int, [vp, vp]),
     "svbgpu_decode": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]),
     "svbgpu_decode_plan": (C.c_int, [C.c_int, vp, C.c_uint32, vp, C.c_size_t, vp]),

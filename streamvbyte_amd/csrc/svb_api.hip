@@ -148,12 +148,35 @@ int run_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out
   return SVBGPU_OK;
 }
 
+size_t g_ws_bytes_hint = 0;
+unsigned g_debug = 0;  // timing-only ablations (wrong results!), see svbgpu_set_option
+int g_encode_qw = 4;  // wave tiles per wave in k_encode (1, 2 or 4); see svbgpu_set_option
+
+template <int V, bool D, bool Z, int QW>
+void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
+                      uint64_t* d_written, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  constexpr unsigned long long kTileInts = (unsigned long long)kWaves * QW * kWtInts;
+  const unsigned full_tiles = (unsigned)(count / kTileInts);
+  const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
+  WsHeader* h = ws_hdr(ws);
+  u64* status = ws_at<u64>(ws, L.off_status);
+  // diagnostic stamps live behind the regular workspace when the caller over-allocated it
+  u64* stamps = (g_debug & 16u) && g_ws_bytes_hint >= L.total + 40ull * (full_tiles + 2)
+                    ? ws_at<u64>(ws, L.total) : nullptr;
+  if (full_tiles)
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true>), dim3(full_tiles), dim3(kBlock), 0, st, d_in, count,
+                       d_out, prev, h, status, d_written, g_debug, stamps);
+  if (ragged)  // the one tile that runs past the end of the stream: same ticket, same look-back words
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false>), dim3(1), dim3(kBlock), 0, st, d_in, count,
+                       d_out, prev, h, status, d_written, g_debug, stamps);
+}
 template <int V, bool D, bool Z>
 void launch_encode(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                    uint64_t* d_written, hipStream_t st) {
-  const WsLayout L = ws_layout(count);
-  hipLaunchKernelGGL((k_encode<V, D, Z>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count,
-                     d_out, prev, ws_hdr(ws), ws_at<u64>(ws, L.off_status), d_written);
+  if (g_encode_qw == 1) launch_encode_qw<V, D, Z, 1>(d_in, count, d_out, prev, ws, d_written, st);
+  else if (g_encode_qw == 2) launch_encode_qw<V, D, Z, 2>(d_in, count, d_out, prev, ws, d_written, st);
+  else launch_encode_qw<V, D, Z, 4>(d_in, count, d_out, prev, ws, d_written, st);
 }
 template <int V, bool D, bool Z>
 void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* d_bytes,
@@ -197,6 +220,20 @@ const char* svbgpu_strerror(int code) {
 }
 
 int svbgpu_device_ok(void) { return dev_info().ok ? 1 : 0; }
+
+int svbgpu_set_option(const char* name, int value) {
+  if (!name) return SVBGPU_EINVAL;
+  if (!std::strcmp(name, "debug_ablate")) {
+    g_debug = (unsigned)value;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "encode_tile")) {
+    if (value != 1 && value != 2 && value != 4) return SVBGPU_EINVAL;
+    g_encode_qw = value;
+    return SVBGPU_OK;
+  }
+  return SVBGPU_EINVAL;
+}
 
 size_t svbgpu_workspace_bytes(uint32_t count) { return ws_layout(count).total; }
 
@@ -263,6 +300,7 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t co
   if (rc) return rc;
   rc = clear_lookback(count, ws, S(stream));
   if (rc) return rc;
+  g_ws_bytes_hint = ws_bytes;
   DISPATCH_VDZ(launch_encode, variant, flags, d_in, count, d_out, prev, ws, d_written, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;

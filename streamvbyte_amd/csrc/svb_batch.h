@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_encode_batch(
       const u64 int0 = (u64)wt * kWtInts;
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
       uint4 x[4];
+      u32 g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = load_group(in, int0 + 4u * (j * 64 + lane), count);
 #pragma unroll
@@ -86,9 +87,12 @@ __global__ __launch_bounds__(kBlock) void k_encode_batch(
           c = make_uint4(c.x - p, c.y - c.x, c.z - c.y, c.w - c.z);
         }
         if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
+        const u64 first = int0 + 4u * (j * 64 + lane);
+        if (DELTA || ZZ) zero_absent(c, first, count);
         x[j] = c;
+        g[j] = classify_group<V>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
       }
-      doff += encode_wavetile<V>(x, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
+      doff += encode_wavetile<V, false>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
     }
     if (lane == 0) sizes[s] = count ? keylen + doff : 0;
   }

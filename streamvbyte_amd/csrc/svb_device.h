@@ -175,7 +175,7 @@ __host__ __device__ inline WsLayout ws_layout(u32 count) {
   L.n_tiles = (L.n_wt + kLbWt - 1) / kLbWt;
   size_t o = sizeof(WsHeader);
   // the look-back words follow the header so one memset clears both
-  L.off_status = o;    o += align256(8 * (L.n_tiles + 1));
+  L.off_status = o;    o += align256(8 * (L.n_wt / kWaves + 2));  // room for the smallest tile size
   L.off_super_off = o; o += align256(8 * (L.n_super + 1));
   L.off_wt_rel = o;    o += align256(4 * L.n_wt);
   L.off_super_sum = o; o += align256(4 * L.n_super);

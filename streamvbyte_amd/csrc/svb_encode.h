@@ -1,17 +1,18 @@
-// Encode path: classify, pack keys, scan lengths, scatter data bytes via LDS.
+// Encode path: classify, pack keys, scan lengths, assemble data bytes in LDS.
 //
 // Replaces the serial encoder loops of the reference
 // (src/streamvbyte_x64_encode.c:15-29,55-97; scalar src/streamvbyte_encode.c:14-62;
 // 0124 src/streamvbyte_0124_encode.c:12-57,61-113; delta
 // src/streamvbytedelta_x64_encode.c:13-75, src/streamvbytedelta_encode.c:39-76).
 //
-// One workgroup = one tile of 16 wave tiles (16384 values); wave w owns wave
-// tiles 4w..4w+3.  Pass 1 loads the 64 values of every lane into registers and
-// sums their widths; the tile's byte count is published and the tile's data
-// offset obtained by decoupled look-back; pass 2 scatters the data bytes of one
-// wave tile at a time into a wave-private LDS image laid out on the 16-byte
-// grid of the destination, then copies it out with aligned 16-byte stores
-// (byte stores for the ragged head and tail, which neighbouring waves share).
+// One workgroup = one tile of 4*QW wave tiles; wave w owns QW consecutive wave
+// tiles.  Pass 1 loads the wave's values into registers, classifies them once
+// (a one-register descriptor per group) and sums their widths; the tile's byte
+// count is published and the tile's data offset obtained by decoupled
+// look-back; pass 2 assembles the data bytes of one wave tile at a time in a
+// wave-private LDS image laid out on the 16-byte grid of the destination and
+// copies it out with aligned 16-byte stores (byte stores for the ragged head
+// and tail, which neighbouring waves share).
 // HBM traffic per value: 4 (in) + 0.25 (keys) + dbar (data).
 #pragma once
 #include "svb_device.h"
@@ -20,11 +21,11 @@
 namespace svb {
 
 struct __align__(16) EncWaveLds {
-  u8 data[kWtDataMax + 32];  // image of one wave tile's data bytes (+16 alignment shift)
+  u8 data[kWtDataMax + 48];  // image of one wave tile's data bytes (+16 alignment shift, +slack)
   u8 keys[kWtKeys];
 };
 
-// Load the 4 values of group `g` (global value index first = 4*g) with bounds.
+// Load the 4 values of the group starting at value index `first`, with bounds.
 __device__ __forceinline__ uint4 load_group(const u32* __restrict__ in, u64 first, u32 count) {
   uint4 x = make_uint4(0, 0, 0, 0);
   if (first + 4 <= count) {
@@ -37,39 +38,84 @@ __device__ __forceinline__ uint4 load_group(const u32* __restrict__ in, u64 firs
   return x;
 }
 
-// Key byte and packed per-value lengths (4 x 8 bit) of one group with `nv`
-// valid values (absent values: code 0, no bytes).
+// Width code from the position of the highest set bit (one v_ffbh instead of
+// three compares).  Same result as code_of<V>.
 template <int V>
-__device__ __forceinline__ void classify_group(const uint4& x, u32 nv, u32& key, u32& lens) {
+__device__ __forceinline__ u32 code_fast(u32 v) {
+  const u32 top = 31u - (u32)__clz((int)(v | 1u));  // index of the highest set bit, 0 for v<2
+  if (V == V1234) return top >> 3;
+  return v ? min((top >> 3) + 1u, 3u) : 0u;
+}
+
+// Group descriptor in one register:
+//   bits  7..0   key (four 2-bit codes)
+//   bits 23..8   data length of each value, 4 bits apiece (0..4; absent values 0)
+//   bits 28..24  data length of the group (0..16)
+__device__ __forceinline__ u32 gi_key(u32 g) { return g & 0xFFu; }
+__device__ __forceinline__ u32 gi_len(u32 g, int k) { return (g >> (8 + 4 * k)) & 0xFu; }
+__device__ __forceinline__ u32 gi_total(u32 g) { return g >> 24; }
+
+template <int V>
+__device__ __forceinline__ u32 classify_group(const uint4& x, u32 nv) {
   const u32 v[4] = {x.x, x.y, x.z, x.w};
-  key = 0;
-  lens = 0;
+  u32 key = 0, lens = 0, tot = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const bool ok = (u32)k < nv;
-    const u32 c = ok ? code_of<V>(v[k]) : 0u;
-    const u32 l = ok ? len_of<V>(c) : 0u;
+    u32 c = code_fast<V>(v[k]);
+    u32 l = len_of<V>(c);
+    if ((u32)k >= nv) { c = 0; l = 0; }  // folds away when nv is the constant 4
     key |= c << (2 * k);
-    lens |= l << (8 * k);
+    lens |= l << (4 * k);
+    tot += l;
   }
+  return key | (lens << 8) | (tot << 24);
+}
+
+// Concatenate the data bytes of a group: the low len[k] bytes of each value,
+// value 0 first, into 128 bits (d[0] = first four bytes).  Values must already
+// be < 256^len (true for every classified value; absent values are zero).
+__device__ __forceinline__ void pack_group(const uint4& x, u32 g, u32 (&d)[4]) {
+  const u32 b0 = gi_len(g, 0) * 8u, b1 = gi_len(g, 1) * 8u, b2 = gi_len(g, 2) * 8u;
+  const u64 lo = (u64)x.x | ((u64)x.y << b0);  // b0 <= 32
+  const u64 hi = (u64)x.z | ((u64)x.w << b2);
+  const u32 s = b0 + b1;                       // 0..64 bits taken by values 0 and 1
+  const u64 vlo = lo | (s < 64u ? hi << s : 0ull);
+  const u64 vhi = s == 0u ? 0ull : (s < 64u ? hi >> (64u - s) : hi);
+  d[0] = (u32)vlo; d[1] = (u32)(vlo >> 32); d[2] = (u32)vhi; d[3] = (u32)(vhi >> 32);
+}
+
+// Dword `i` (0..4) of the group's bytes once shifted to start at byte (p & 3)
+// of an aligned dword.
+__device__ __forceinline__ u32 shifted_dword(const u32 (&d)[4], int i, u32 a8) {
+  const u32 lo = i == 0 ? 0u : d[i - 1];
+  const u32 hi = i == 4 ? 0u : d[i];
+  return (u32)(((((u64)hi) << 32) | lo) << a8 >> 32);
+}
+
+// 0124: OR the group's bytes into the zeroed LDS image at byte offset p.  An
+// image dword can be shared by several neighbouring groups (0124 groups can be
+// empty) whose bytes are disjoint, so an LDS atomic OR assembles it whatever
+// the order.
+__device__ __forceinline__ void or_into_image(u8* image, u32 p, u32 L, const u32 (&d)[4]) {
+  const u32 a8 = 8u * (p & 3u);
+  u32* q = reinterpret_cast<u32*>(image + (p & ~3u));
+  const u32 nd = (L + (p & 3u) + 3u) >> 2;  // dwords touched, 0..5
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+    if (nd > (u32)i) atomicOr(q + i, shifted_dword(d, i, a8));
 }
 
 // One wave tile, values -> bytes.  x[j] holds group j*64+lane (already delta /
-// zigzag transformed), `nints` of the tile's 1024 values exist.  Scatters the
-// data bytes into the wave's LDS image, copies them to dst[0..total) and the
-// (nints+3)/4 keys to kdst.  Returns total.
-template <int V>
-__device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], u32 nints, int lane,
-                                               EncWaveLds& S, u8* dst, u8* kdst) {
-  u32 key[4], lens[4];
+// zigzag transformed, absent values zero) and g[j] its descriptor; `nints` of
+// the tile's 1024 values exist (FULL: all of them).  Assembles the data bytes
+// in the wave's LDS image, copies them to dst[0..total) and the keys to kdst.
+// Returns total.
+template <int V, bool FULL>
+__device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&g)[4], u32 nints,
+                                               int lane, EncWaveLds& S, u8* dst, u8* kdst) {
   u64 packed = 0;  // 4 x 16-bit group lengths, one per j
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const u32 first = 4u * (j * 64 + lane);
-    const u32 nv = first < nints ? min(4u, nints - first) : 0u;
-    classify_group<V>(x[j], nv, key[j], lens[j]);
-    packed |= (u64)((lens[j] * 0x01010101u) >> 24) << (16 * j);
-  }
+  for (int j = 0; j < 4; ++j) packed |= (u64)gi_total(g[j]) << (16 * j);
   // one 64-bit wave scan gives, per j, the inclusive prefix over lanes
   u64 incl = packed;
 #pragma unroll
@@ -80,24 +126,57 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], u32 nints, i
   const u64 tots = __shfl(incl, 63, 64);
   const u64 excl = incl - packed;
   const u32 a = (u32)((uintptr_t)dst & 15u);  // LDS image byte i+a <-> dst[i]
-  u32 jbase = 0;
+  const u32 t0 = (u32)(tots & 0xFFFFu), t1 = (u32)((tots >> 16) & 0xFFFFu),
+            t2 = (u32)((tots >> 32) & 0xFFFFu), t3 = (u32)(tots >> 48);
+  const u32 total = t0 + t1 + t2 + t3;
+  u32 p[4];
+  p[0] = a + (u32)(excl & 0xFFFFu);
+  p[1] = a + t0 + (u32)((excl >> 16) & 0xFFFFu);
+  p[2] = a + t0 + t1 + (u32)((excl >> 32) & 0xFFFFu);
+  p[3] = a + t0 + t1 + t2 + (u32)(excl >> 48);
+  u32 d[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    u32 p = a + jbase + (u32)((excl >> (16 * j)) & 0xFFFFu);
-    jbase += (u32)((tots >> (16 * j)) & 0xFFFFu);
-    const u32 v[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const u32 l = (lens[j] >> (8 * k)) & 0xFFu;
-      if (l > 0) S.data[p] = (u8)v[k];
-      if (l > 1) S.data[p + 1] = (u8)(v[k] >> 8);
-      if (l > 2) S.data[p + 2] = (u8)(v[k] >> 16);
-      if (l > 3) S.data[p + 3] = (u8)(v[k] >> 24);
-      p += l;
-    }
-    S.keys[j * 64 + lane] = (u8)key[j];
+    pack_group(x[j], g[j], d[j]);
+    S.keys[j * 64 + lane] = (u8)gi_key(g[j]);
   }
-  const u32 total = jbase;
+
+  if (V == V1234) {
+    // Plain aligned dword stores, no atomics.  A dword on the border of two
+    // groups is written by both (1234 groups have >= 4 bytes, so never by
+    // three): by the later group as its dword 0, by the earlier one as its last
+    // dword, index >= 1.  Stores are issued dword index by dword index over all
+    // four quarters, so the earlier group's store lands last and the border
+    // dword ends up with its tail bytes and zeros where the later group's first
+    // 1..3 bytes belong.  Those are then written again, byte by byte, by every
+    // lane for its own group (the first three bytes of a 1234 group always
+    // exist).  LDS executes one wave's stores in program order.  Groups without
+    // bytes (past the end of the stream) store nothing.
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 L = gi_total(g[j]);
+        const u32 nd = (FULL || L) ? (L + (p[j] & 3u) + 3u) >> 2 : 0u;
+        u32* q = reinterpret_cast<u32*>(S.data + (p[j] & ~3u));
+        if (nd > (u32)i) q[i] = shifted_dword(d[j], i, 8u * (p[j] & 3u));
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (FULL || gi_total(g[j])) {
+        S.data[p[j]] = (u8)d[j][0];
+        S.data[p[j] + 1] = (u8)(d[j][0] >> 8);
+        S.data[p[j] + 2] = (u8)(d[j][0] >> 16);
+      }
+    }
+  } else {
+    // zero the image: [0, a+total) rounded up to whole 16-byte chunks
+    const u32 nz = (a + total + 15u) >> 4;  // <= 258
+    uint4* l16 = reinterpret_cast<uint4*>(S.data);
+    for (u32 c = lane; c < nz; c += 64) l16[c] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) or_into_image(S.data, p[j], gi_total(g[j]), d[j]);
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
@@ -122,7 +201,7 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], u32 nints, i
   }
   // keys
   {
-    const u32 nkeys = (nints + 3u) >> 2;
+    const u32 nkeys = FULL ? (u32)kWtKeys : ((nints + 3u) >> 2);
     if ((((uintptr_t)kdst) & 3u) == 0 && 4u * lane + 4u <= nkeys) {
       *reinterpret_cast<u32*>(kdst + 4 * lane) = reinterpret_cast<const u32*>(S.keys)[lane];
     } else {
@@ -135,12 +214,26 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], u32 nints, i
   return total;
 }
 
-template <int V, bool DELTA, bool ZZ>
-__global__ __launch_bounds__(kBlock, 4) void k_encode(const u32* __restrict__ in, u32 count,
-                                                      u8* __restrict__ out, u32 prev,
-                                                      WsHeader* __restrict__ hdr,
-                                                      u64* __restrict__ status,
-                                                      u64* __restrict__ written) {
+// Absent values (past the end of the stream) must be zero before packing.
+__device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
+  if (first + 4 > count) {
+    if (first + 3 >= count) c.w = 0;
+    if (first + 2 >= count) c.z = 0;
+    if (first + 1 >= count) c.y = 0;
+    if (first >= count) c.x = 0;
+  }
+}
+
+// k_encode<.., FULL=true> handles the tiles that lie wholly inside the stream
+// (one workgroup each, no bounds logic); the one ragged tile at the end, if any,
+// is a second single-workgroup launch of the FULL=false instantiation on the
+// same stream, continuing the same ticket and look-back words.
+// QW = wave tiles per wave; the workgroup's tile is 4*QW wave tiles.
+template <int V, bool DELTA, bool ZZ, int QW, bool FULL>
+__global__ __launch_bounds__(kBlock, (QW > 2 ? 3 : (QW > 1 ? 4 : 7))) void k_encode(
+    const u32* __restrict__ in, u32 count, u8* __restrict__ out, u32 prev,
+    WsHeader* __restrict__ hdr, u64* __restrict__ status, u64* __restrict__ written, u32 dbg,
+    u64* __restrict__ stamps) {
   __shared__ EncWaveLds s_lds[kWaves];
   __shared__ u32 s_wave_tot[kWaves];
   __shared__ u64 s_prefix;
@@ -149,57 +242,64 @@ __global__ __launch_bounds__(kBlock, 4) void k_encode(const u32* __restrict__ in
   const int lane = lane_id(), wave = wave_id();
   if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
   __syncthreads();
-  const u32 tile = s_tile;
+  const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
+  // diagnostic build only (stamps != nullptr): wall-clock stamps per tile, 100 MHz
+  if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 0] = __builtin_amdgcn_s_memrealtime();
   const u64 keylen = ((u64)count + 3) >> 2;
-  const u64 wave_first = ((u64)tile * kLbWt + (u64)wave * 4) * kWtInts;  // first value of this wave
+  constexpr u64 kTileInts = (u64)kWaves * QW * kWtInts;
+  const u64 wave_first = (u64)tile * kTileInts + (u64)wave * QW * kWtInts;  // first value of this wave
 
-  // ---- pass 1: load, transform, widths ------------------------------------
-  uint4 x[4][4];
+  // ---- pass 1: load, transform, classify -----------------------------------
+  uint4 x[QW][4];
+  u32 g[QW][4];
+  if (FULL) {
+    const uint4* src = reinterpret_cast<const uint4*>(in + wave_first) + lane;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < QW; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      x[q][j] = load_group(in, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count);
-
+      for (int j = 0; j < 4; ++j) x[q][j] = src[q * 256 + j * 64];
+  } else {
+#pragma unroll
+    for (int q = 0; q < QW; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        x[q][j] = load_group(in, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count);
+  }
   if (DELTA) {
     // previous value of the wave's first element, then neighbours by lane shuffles
     u32 carry = prev;
     if (wave_first > 0 && wave_first <= count) carry = in[wave_first - 1];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < QW; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint4 c = x[q][j];
-        u32 p = __shfl_up(c.w, 1, 64);
-        if (lane == 0) p = carry;
+        u32 pv = __shfl_up(c.w, 1, 64);
+        if (lane == 0) pv = carry;
         carry = __shfl(c.w, 63, 64);
-        x[q][j] = make_uint4(c.x - p, c.y - c.x, c.z - c.y, c.w - c.z);
+        x[q][j] = make_uint4(c.x - pv, c.y - c.x, c.z - c.y, c.w - c.z);
       }
   }
-  if (ZZ) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint4& c = x[q][j];
-        c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
-      }
-  }
-
   u32 lane_tot = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < QW; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const u64 first = wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane);
-      const u32 nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
-      u32 key, lens;
-      classify_group<V>(x[q][j], nv, key, lens);
-      lane_tot += (lens * 0x01010101u) >> 24;
+      uint4& c = x[q][j];
+      if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
+      u32 nv = 4u;
+      if (!FULL) {
+        const u64 first = wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane);
+        if (DELTA || ZZ) zero_absent(c, first, count);
+        nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
+      }
+      g[q][j] = classify_group<V>(c, nv);
+      lane_tot += gi_total(g[q][j]);
     }
   const u32 wave_tot = wave_sum(lane_tot);
   if (lane == 0) s_wave_tot[wave] = wave_tot;
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 1] = __builtin_amdgcn_s_memrealtime();
 
   // ---- tile offset by decoupled look-back ----------------------------------
   if (wave == 0) {
@@ -209,12 +309,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_encode(const u32* __restrict__ in
       if (lane == 0) lb_publish(status, 0, kLbPfx, tile_tot);
     } else {
       if (lane == 0) lb_publish(status, tile, kLbAgg, tile_tot);
-      excl = lb_exclusive_prefix(status, tile, lane, &hdr->error);
+      // smaller tiles are drawn faster, so the window widens with 1/QW (256 .. 1024 tiles)
+      if (!(dbg & 1u)) excl = lb_exclusive_prefix<16 / QW>(status, tile, lane, &hdr->error);
       if (lane == 0) lb_publish(status, tile, kLbPfx, excl + tile_tot);
     }
+    if (stamps && lane == 0) stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       s_prefix = excl;
-      const u64 last_tile = keylen ? (keylen - 1) / ((u64)kLbWt * kWtKeys) : 0;
+      const u64 last_tile = keylen ? (keylen - 1) / ((u64)kWaves * QW * kWtKeys) : 0;
       if (tile == last_tile && written) *written = keylen + excl + tile_tot;
     }
   }
@@ -222,17 +324,21 @@ __global__ __launch_bounds__(kBlock, 4) void k_encode(const u32* __restrict__ in
   u64 doff = s_prefix;
   for (int w = 0; w < wave; ++w) doff += s_wave_tot[w];
 
-  // ---- pass 2: per wave tile, scan -> scatter into LDS -> store ----------------
+  // ---- pass 2: per wave tile, scan -> assemble in LDS -> store -----------------
   EncWaveLds& S = s_lds[wave];
   u8* data_out = out + keylen;
+  if (dbg & 2u) return;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < QW; ++q) {
     const u64 wt_first = wave_first + (u64)q * kWtInts;
-    if (wt_first < count) {
+    if (FULL) {
+      doff += encode_wavetile<V, true>(x[q], g[q], kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
+    } else if (wt_first < count) {
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - wt_first);
-      doff += encode_wavetile<V>(x[q], nints, lane, S, data_out + doff, out + (wt_first >> 2));
+      doff += encode_wavetile<V, false>(x[q], g[q], nints, lane, S, data_out + doff, out + (wt_first >> 2));
     }
   }
+  if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace svb

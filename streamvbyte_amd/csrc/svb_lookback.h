@@ -18,7 +18,6 @@ namespace svb {
 constexpr u64 kLbAgg = 1ull << 62;
 constexpr u64 kLbPfx = 2ull << 62;
 constexpr u64 kLbVal = (1ull << 62) - 1;
-constexpr int kLbWin = 4;               // status words polled per lane and round (window 256)
 constexpr u32 kLbSpinLimit = 1u << 20;  // polls before giving up
 
 __device__ __forceinline__ void lb_publish(u64* status, u32 tile, u64 flag, u64 val) {
@@ -29,6 +28,7 @@ __device__ __forceinline__ void lb_publish(u64* status, u32 tile, u64 flag, u64 
 // Sum of the aggregates of all tiles before `tile` (tile > 0), seeded by the
 // nearest published inclusive prefix.  Must be called by all 64 lanes of one
 // wavefront; returns the same value in every lane.
+template <int kLbWin = 4>  // status words polled per lane and round (window = 64 * kLbWin tiles)
 __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, int lane,
                                                    u32* err) {
   u64 prefix = 0;

@@ -43,8 +43,31 @@ enc_out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8,
 if want("decode"):
     ops["decode_plan"] = (lambda: codec.decode_plan(stream, n), 0.25 * n)
     ops["decode_run"] = (lambda: codec.decode_run(stream, n, out), (4.25 + dbar) * n)
+def enc_with(qw, f):
+    def g():
+        codec.lib.svbgpu_set_option(b"encode_tile", qw)
+        f()
+        codec.lib.svbgpu_set_option(b"encode_tile", 4)
+    return g
+
+
+def dbg_with(flag, f):
+    def g():
+        codec.lib.svbgpu_set_option(b"debug_ablate", flag)
+        f()
+        codec.lib.svbgpu_set_option(b"debug_ablate", 0)
+    return g
+
+
+if want("ablate"):
+    ops["encode_nolookback"] = (dbg_with(1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_nopass2"] = (dbg_with(2, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_win1024"] = (dbg_with(4, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_win512"] = (dbg_with(8, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_neither"] = (dbg_with(3, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
 if want("encode"):
-    ops["encode"] = (lambda: codec.encode(values, out=enc_out), (4.25 + dbar) * n)
+    for qw in (1, 2, 4):
+        ops[f"encode_qw{qw}"] = (enc_with(qw, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
 if want("delta"):
     g = torch.Generator(device=dev); g.manual_seed(7)
     post = torch.cumsum(torch.randint(0, 32, (n,), generator=g, device=dev, dtype=torch.int64), 0)
