@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void k_decode_batch(
           c.y += c.x; c.z += c.y; c.w += c.z;
           const u32 incl = wave_scan_incl(c.w, lane);
           const u32 ex = incl - c.w + run;
-          run += __shfl(incl, 63, 64);
+          run += wave_last(incl);
           c.x += ex; c.y += ex; c.z += ex; c.w += ex;
         }
         store_group(out, int0 + 4u * (j * 64 + lane), count, c);
@@ -81,9 +81,8 @@ __global__ __launch_bounds__(kBlock) void k_encode_batch(
       for (int j = 0; j < 4; ++j) {
         uint4 c = x[j];
         if (DELTA) {
-          u32 p = __shfl_up(c.w, 1, 64);
-          if (lane == 0) p = carry;
-          carry = __shfl(c.w, 63, 64);
+          const u32 p = wave_shift_up1(c.w, carry);
+          carry = wave_last(c.w);
           c = make_uint4(c.x - p, c.y - c.x, c.z - c.y, c.w - c.z);
         }
         if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));

@@ -118,7 +118,7 @@ __device__ __forceinline__ u32 scan_keys_to_entries(u32 w, u32 nv, int lane, u32
   e.z = (ex + ((P >> 16) & 0xFFu)) | (((w >> 16) & 0xFFu) << 16);
   e.w = (ex + (P >> 24)) | ((w >> 24) << 16);
   *reinterpret_cast<uint4*>(ent + 4 * lane) = e;
-  return __shfl(incl, 63, 64);
+  return wave_last(incl);
 }
 
 // Stage the contiguous data span [dp, dp+total) into LDS with aligned 16-byte

@@ -30,7 +30,7 @@ __device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[4][4], int lane) {
       c.w += c.z;
       const u32 incl = wave_scan_incl(c.w, lane);
       const u32 ex = incl - c.w + run;
-      run += __shfl(incl, 63, 64);
+      run += wave_last(incl);
       c.x += ex; c.y += ex; c.z += ex; c.w += ex;
     }
   return run;
@@ -63,7 +63,7 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
 }
 
 template <int V, bool ZZ>
-__global__ __launch_bounds__(kBlock, 4) void k_delta_decode(
+__global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
     const u64* __restrict__ super_off, const u32* __restrict__ wt_rel, WsHeader* __restrict__ hdr,
     u64* __restrict__ status, u64* __restrict__ consumed) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_delta_decode(
 // Plain inclusive running sum out[i] = seed + sum_{j<=i} f(in[j]), f = identity
 // or un-zigzag (zigzag_delta_decode).  8 B per value.
 template <bool ZZ>
-__global__ __launch_bounds__(kBlock, 4) void k_running_sum(const u32* __restrict__ in,
+__global__ __launch_bounds__(kBlock, 3) void k_running_sum(const u32* __restrict__ in,
                                                            u32* __restrict__ out, u32 count,
                                                            u32 seed, WsHeader* __restrict__ hdr,
                                                            u64* __restrict__ status) {

@@ -59,20 +59,31 @@ __device__ __forceinline__ u32 lds_u32_aligned(const u8* base, u32 p) {
   return __builtin_amdgcn_alignbyte(hi, lo, p);
 }
 
+// ---- cross-lane primitives on DPP (no LDS traffic) ------------------------------
+// row_shr:n moves data n lanes up inside each row of 16 lanes (zero shifted in),
+// row_bcast:15 / :31 carry the last lane of a row / of the lower half-wave into
+// the following row(s): six DPP adds make a 64-lane inclusive scan.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_zero(u32 x) {
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
+}
 // Inclusive prefix sum over the 64 lanes of a wavefront.
-__device__ __forceinline__ u32 wave_scan_incl(u32 x, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    u32 y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
+__device__ __forceinline__ u32 wave_scan_incl(u32 x, int /*lane*/) {
+  x += dpp_zero<0x111, 0xF>(x);  // row_shr:1
+  x += dpp_zero<0x112, 0xF>(x);  // row_shr:2
+  x += dpp_zero<0x114, 0xF>(x);  // row_shr:4
+  x += dpp_zero<0x118, 0xF>(x);  // row_shr:8
+  x += dpp_zero<0x142, 0xA>(x);  // row_bcast:15 into rows 1 and 3
+  x += dpp_zero<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
   return x;
 }
-__device__ __forceinline__ u32 wave_sum(u32 x) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
-  return x;
+// Value of lane 63 (wave-uniform).
+__device__ __forceinline__ u32 wave_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
+// Value of the previous lane; lane 0 receives `first`.
+__device__ __forceinline__ u32 wave_shift_up1(u32 x, u32 first) {
+  return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xF, 0xF, false);  // wave_shr:1
 }
+__device__ __forceinline__ u32 wave_sum(u32 x) { return wave_last(wave_scan_incl(x, 0)); }
 __device__ __forceinline__ u64 wave_sum64(u64 x) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);

@@ -116,14 +116,11 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&
   u64 packed = 0;  // 4 x 16-bit group lengths, one per j
 #pragma unroll
   for (int j = 0; j < 4; ++j) packed |= (u64)gi_total(g[j]) << (16 * j);
-  // one 64-bit wave scan gives, per j, the inclusive prefix over lanes
-  u64 incl = packed;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const u64 y = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += y;
-  }
-  const u64 tots = __shfl(incl, 63, 64);
+  // the four 16-bit fields never carry into each other (a field sums to at most
+  // 64*16), so two 32-bit scans give, per j, the inclusive prefix over lanes
+  const u32 inc_lo = wave_scan_incl((u32)packed, lane), inc_hi = wave_scan_incl((u32)(packed >> 32), lane);
+  const u64 incl = ((u64)inc_hi << 32) | inc_lo;
+  const u64 tots = ((u64)wave_last(inc_hi) << 32) | wave_last(inc_lo);
   const u64 excl = incl - packed;
   const u32 a = (u32)((uintptr_t)dst & 15u);  // LDS image byte i+a <-> dst[i]
   const u32 t0 = (u32)(tots & 0xFFFFu), t1 = (u32)((tots >> 16) & 0xFFFFu),
@@ -274,9 +271,8 @@ __global__ __launch_bounds__(kBlock, (QW > 2 ? 3 : (QW > 1 ? 4 : 7))) void k_enc
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint4 c = x[q][j];
-        u32 pv = __shfl_up(c.w, 1, 64);
-        if (lane == 0) pv = carry;
-        carry = __shfl(c.w, 63, 64);
+        const u32 pv = wave_shift_up1(c.w, carry);
+        carry = wave_last(c.w);
         x[q][j] = make_uint4(c.x - pv, c.y - c.x, c.z - c.y, c.w - c.z);
       }
   }
