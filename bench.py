@@ -163,12 +163,18 @@ def cpu_baseline(values_host, threads_all):
     }
 
 
-def gen_posting_lists(torch, nlists, seed, device):
-    """lengths log-uniform on [1,4096]; sorted lists with small gaps (1-2 byte deltas)"""
+def list_lengths(nlists, seed):
+    """lengths log-uniform on [1,4096], the same array on every rank"""
+    u = np.random.default_rng(seed).uniform(0.0, np.log(4096.0), size=nlists)
+    return np.clip(np.floor(np.exp(u)), 1, 4096).astype(np.int64)
+
+
+def gen_posting_lists(torch, counts_np, seed, device):
+    """sorted lists with small gaps (1-2 byte deltas) for the given lengths"""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    u = torch.rand(nlists, generator=g, device=device, dtype=torch.float64)
-    counts = torch.exp(u * np.log(4096.0)).floor().clamp_(1, 4096).to(torch.int64)
+    counts = torch.from_numpy(counts_np).to(device)
+    nlists = counts.numel()
     voff = torch.zeros(nlists + 1, dtype=torch.int64, device=device)
     voff[1:] = torch.cumsum(counts, 0)
     total = int(voff[-1].item())
@@ -255,6 +261,16 @@ def main():
     alg_bytes = (4.25 + dbar) * n  # keys 0.25 + data dbar + output 4 bytes per value
     achieved = alg_bytes / (run_ms * 1e-3) / 1e9
 
+    # HBM bytes per k_decode launch from the committed PMC passes (same kernel,
+    # same 2^28 workload; rocprofv3 counters cannot be collected from inside this process)
+    traffic, traffic_src = None, None
+    if a.log2n == 28:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
+            k = json.load(open(path))["kernels"].get("k_decode<0, false>")
+            if k:
+                traffic, traffic_src = k["hbm_bytes"], os.path.relpath(path, ROOT)
+
     res = {
         "metric": "device-resident decode GB/s (uint32 out)",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -268,7 +284,7 @@ def main():
         "parity": "bit-exact" if parity else "MISMATCH",
         "roofline": {"bound": "hbm", "kernel": "k_decode<1234>", "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes),
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg_bytes),
                      "kernel_ms": round(run_ms, 4), "directory_ms": round(plan_ms, 4),
                      "whole_step_frac": round((alg_bytes + 0.25 * n) / (t / a.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
@@ -332,8 +348,11 @@ def main():
         res["extra"] = extra
 
         # ---- batched posting lists, sharded over ranks ----------------------------
-        nl = a.lists // world
-        counts, voff, vals = gen_posting_lists(torch, nl, 1234 + rank, device)
+        from streamvbyte_amd.sharding import partition_streams, all_gather_sizes
+        lengths = list_lengths(a.lists, 20241218)
+        cut = partition_streams(lengths, world)  # whole lists per rank, balanced by value count
+        nl = int(cut[rank + 1] - cut[rank])
+        counts, voff, vals = gen_posting_lists(torch, lengths[cut[rank]:cut[rank + 1]], 1234 + rank, device)
         tot = int(voff[-1].item())
         cap = (counts.to(torch.int64) + 3) // 4 + 4 * counts.to(torch.int64) + 16
         boff = torch.zeros(nl + 1, dtype=torch.int64, device=device)
@@ -341,12 +360,12 @@ def main():
         bbuf = torch.empty(int(boff[-1].item()) + 16, dtype=torch.uint8, device=device)
         back = torch.empty_like(vals)
         sizes = torch.empty(nl, dtype=torch.int64, device=device)
-        gathered = [torch.empty(nl, dtype=torch.int64, device=device) for _ in range(world)] if dist else None
+        directory = {}
 
         def enc_batch():
             codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=svb.DELTA, sizes=sizes)
-            if dist:
-                dist.all_gather(gathered, sizes)  # per-stream sizes -> global directory (RCCL)
+            if dist:  # per-stream sizes -> global byte directory (RCCL all-gather, 8 B per list)
+                directory["sizes"], directory["offsets"] = all_gather_sizes(dist, sizes, cut)
 
         def dec_batch():
             codec.decode_batch(bbuf, boff[:-1], back, voff[:-1], counts, None, flags=svb.DELTA)
@@ -360,8 +379,9 @@ def main():
             dist.all_reduce(tot_t)
         tot_all = int(tot_t.item())
         dB = float((sizes.sum().item() - ((counts.to(torch.int64) + 3) // 4).sum().item()) / tot)
-        res["batched"] = {"workload": f"{nl * world} posting lists (log-uniform 1..4096 values), delta coded, "
-                                      f"sharded {nl} per GPU, RCCL all-gather of sizes" + ("" if dist else " (1 rank: no collective)"),
+        res["batched"] = {"workload": f"{a.lists} posting lists (log-uniform 1..4096 values), delta coded, whole lists "
+                                      f"sharded over {world} GPU(s) by value count, RCCL all-gather of sizes"
+                                      + ("" if dist else " (1 rank: no collective)"),
                           "values": tot_all, "data_bytes_per_value": round(dB, 4), "parity": okb,
                           "decode_GBps": round(4.0 * tot_all * kb / tb_d / 1e9, 1),
                           "encode_GBps": round(4.0 * tot_all * kb / tb_e / 1e9, 1),

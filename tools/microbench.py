@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import streamvbyte_amd as svb  # noqa: E402
-from bench import gen_width_mix, gen_posting_lists  # noqa: E402
+from bench import gen_width_mix, gen_posting_lists, list_lengths  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2n", type=int, default=28)
@@ -95,7 +95,7 @@ if want("misc"):
     ops["zigzag_delta_dec"] = (lambda: codec.zigzag(values, "delta_decode", out=tmpz), 8.0 * n)
 if want("batch"):
     nl = 1 << 20
-    counts, voff, vals = gen_posting_lists(torch, nl, 1234, dev)
+    counts, voff, vals = gen_posting_lists(torch, list_lengths(nl, 20241218), 1234, dev)
     tot = int(voff[-1].item())
     cap = (counts.to(torch.int64) + 3) // 4 + 4 * counts.to(torch.int64) + 16
     boff = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
