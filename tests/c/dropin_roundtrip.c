@@ -1,0 +1,39 @@
+/* A plain C caller of the reference API: compiled with gcc against include/ and
+ * linked against libstreamvbyte.so.2, with no knowledge of HIP.  Exit 0 = ok. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "streamvbyte.h"
+#include "streamvbyte_zigzag.h"
+#include "streamvbytedelta.h"
+
+int main(void) {
+  const uint32_t n = 100003;
+  uint32_t *in = malloc(n * sizeof(uint32_t)), *back = malloc(n * sizeof(uint32_t));
+  uint8_t *buf = malloc(streamvbyte_max_compressedbytes(n));
+  uint32_t x = 12345;
+  for (uint32_t i = 0; i < n; i++) {
+    x = x * 1664525u + 1013904223u;
+    in[i] = x >> (x & 31u);
+  }
+  size_t a = streamvbyte_encode(in, n, buf);
+  if (a != streamvbyte_compressedbytes(in, n)) return 1;
+  if (!streamvbyte_validate_stream(buf, a, n)) return 2;
+  if (streamvbyte_decode(buf, back, n) != a || memcmp(in, back, n * 4)) return 3;
+  a = streamvbyte_encode_0124(in, n, buf);
+  if (a != streamvbyte_compressedbytes_0124(in, n)) return 4;
+  if (!streamvbyte_validate_stream_0124(buf, a, n)) return 5;
+  if (streamvbyte_decode_0124(buf, back, n) != a || memcmp(in, back, n * 4)) return 6;
+  a = streamvbyte_delta_encode(in, n, buf, 77);
+  if (streamvbyte_delta_decode(buf, back, n, 77) != a || memcmp(in, back, n * 4)) return 7;
+  zigzag_encode((const int32_t *)in, back, n);
+  zigzag_decode(back, (int32_t *)back, n);
+  if (memcmp(in, back, n * 4)) return 8;
+  zigzag_delta_encode((const int32_t *)in, back, n, -3);
+  uint32_t *tmp = malloc(n * 4);
+  zigzag_delta_decode(back, (int32_t *)tmp, n, -3);
+  if (memcmp(in, tmp, n * 4)) return 9;
+  printf("drop-in round trips ok (%zu bytes)\n", a);
+  return 0;
+}

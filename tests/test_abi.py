@@ -64,3 +64,27 @@ def test_missing_library_is_an_error(monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libstreamvbyte.so.2")
     with pytest.raises(RuntimeError):
         L.load()
+
+
+def _build_c_caller(tmp_path):
+    import streamvbyte_amd
+    exe = str(tmp_path / "dropin_roundtrip")
+    libdir = os.path.dirname(streamvbyte_amd.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", INCLUDE,
+           os.path.join(ROOT, "tests", "c", "dropin_roundtrip.c"), "-o", exe,
+           "-L", libdir, "-l:libstreamvbyte.so.2", f"-Wl,-rpath,{libdir}",
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_plain_c_caller_compiles_and_links(tmp_path):
+    """A C99 program using only the reference's headers builds against the library."""
+    _build_c_caller(tmp_path)
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_runs(tmp_path):
+    exe = _build_c_caller(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
