@@ -306,7 +306,9 @@ __global__ __launch_bounds__(kBlock, (QW > 2 ? 3 : (QW > 1 ? 4 : 7))) void k_enc
     } else {
       if (lane == 0) lb_publish(status, tile, kLbAgg, tile_tot);
       // smaller tiles are drawn faster, so the window widens with 1/QW (256 .. 1024 tiles)
-      if (!(dbg & 1u)) excl = lb_exclusive_prefix<16 / QW>(status, tile, lane, &hdr->error);
+      u32 rounds = 0;
+      if (!(dbg & 1u)) excl = lb_exclusive_prefix<16 / QW>(status, tile, lane, &hdr->error, &rounds);
+      if (stamps && lane == 0) stamps[5 * (u64)tile + 4] = rounds;
       if (lane == 0) lb_publish(status, tile, kLbPfx, excl + tile_tot);
     }
     if (stamps && lane == 0) stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();

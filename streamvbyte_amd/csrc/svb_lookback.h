@@ -30,11 +30,12 @@ __device__ __forceinline__ void lb_publish(u64* status, u32 tile, u64 flag, u64 
 // wavefront; returns the same value in every lane.
 template <int kLbWin = 4>  // status words polled per lane and round (window = 64 * kLbWin tiles)
 __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, int lane,
-                                                   u32* err) {
+                                                   u32* err, u32* rounds_out = nullptr) {
   u64 prefix = 0;
   long long base = (long long)tile - 1;  // nearest predecessor not yet summed
-  u32 spins = 0;
+  u32 spins = 0, rounds = 0;
   while (true) {
+    ++rounds;
     u64 s[kLbWin];
 #pragma unroll
     for (int i = 0; i < kLbWin; ++i) {
@@ -72,6 +73,7 @@ __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, 
       }
     }
   }
+  if (rounds_out) *rounds_out = rounds;
   return prefix;
 }
 

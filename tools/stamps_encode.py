@@ -32,6 +32,8 @@ print(f"tiles {tiles}  kernel span {done.max():.1f} us")
 for name, v in (("load+classify", loaded - start), ("lookback", resolved - loaded), ("pass2", done - resolved), ("total", done - start)):
     print(f"{name:14s} mean {v.mean():7.2f}  p10 {np.percentile(v,10):7.2f}  p50 {np.percentile(v,50):7.2f}  p90 {np.percentile(v,90):7.2f}  max {v.max():7.2f} us")
 # how long after the predecessor resolved did this tile resolve, and after own publish?
+r = st[1:, 4]
+print("poll rounds: mean %.2f p50 %.0f p90 %.0f max %.0f; lookback us per round p50 %.2f" % (r.mean(), np.percentile(r,50), np.percentile(r,90), r.max(), np.percentile((resolved-loaded)[1:]/np.maximum(r,1),50)))
 print("resolve(i) - resolve(i-1): p50 %.3f p90 %.3f us" % (np.percentile(np.diff(resolved), 50), np.percentile(np.diff(resolved), 90)))
 print("resolved - max(loaded(i), loaded(i-1)): p50 %.2f p90 %.2f us" % tuple(np.percentile(resolved[1:] - np.maximum(loaded[1:], loaded[:-1]), [50, 90])))
 for lo in (0, tiles // 2, tiles - 12):
