@@ -227,7 +227,7 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // same stream, continuing the same ticket and look-back words.
 // QW = wave tiles per wave; the workgroup's tile is 4*QW wave tiles.
 template <int V, bool DELTA, bool ZZ, int QW, bool FULL>
-__global__ __launch_bounds__(kBlock, (QW > 2 ? 3 : (QW > 1 ? 4 : 7))) void k_encode(
+__global__ __launch_bounds__(kBlock, (QW > 2 ? (ZZ || V != V1234 ? 3 : 4) : (QW > 1 ? 5 : 7))) void k_encode(
     const u32* __restrict__ in, u32 count, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, u64* __restrict__ status, u64* __restrict__ written, u32 dbg,
     u64* __restrict__ stamps) {
@@ -252,9 +252,14 @@ __global__ __launch_bounds__(kBlock, (QW > 2 ? 3 : (QW > 1 ? 4 : 7))) void k_enc
   if (FULL) {
     const uint4* src = reinterpret_cast<const uint4*>(in + wave_first) + lane;
 #pragma unroll
-    for (int q = 0; q < QW; ++q)
+    for (int q = 0; q < QW; ++q) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[q][j] = src[q * 256 + j * 64];
+      if ((dbg & 32u) && (q & 1)) {  // experiment: at most two wave tiles of loads in flight per wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   } else {
 #pragma unroll
     for (int q = 0; q < QW; ++q)
@@ -326,15 +331,26 @@ __global__ __launch_bounds__(kBlock, (QW > 2 ? 3 : (QW > 1 ? 4 : 7))) void k_enc
   EncWaveLds& S = s_lds[wave];
   u8* data_out = out + keylen;
   if (dbg & 2u) return;
-#pragma unroll
+  // A rolled loop: the wave tile being emitted is always x[0] / g[0], the rest
+  // rotate down by register moves.  This keeps one iteration's temporaries from
+  // overlapping the next one's (an unrolled loop costs ~40 more VGPRs and a
+  // workgroup per CU).
+#pragma unroll 1
   for (int q = 0; q < QW; ++q) {
     const u64 wt_first = wave_first + (u64)q * kWtInts;
     if (FULL) {
-      doff += encode_wavetile<V, true>(x[q], g[q], kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
+      doff += encode_wavetile<V, true>(x[0], g[0], kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
     } else if (wt_first < count) {
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - wt_first);
-      doff += encode_wavetile<V, false>(x[q], g[q], nints, lane, S, data_out + doff, out + (wt_first >> 2));
+      doff += encode_wavetile<V, false>(x[0], g[0], nints, lane, S, data_out + doff, out + (wt_first >> 2));
     }
+#pragma unroll
+    for (int r = 0; r + 1 < QW; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[r][j] = x[r + 1][j];
+        g[r][j] = g[r + 1][j];
+      }
   }
   if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 3] = __builtin_amdgcn_s_memrealtime();
 }

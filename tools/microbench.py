@@ -64,6 +64,7 @@ if want("ablate"):
     ops["encode_nopass2"] = (dbg_with(2, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_win1024"] = (dbg_with(4, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_win512"] = (dbg_with(8, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_batched_loads"] = (dbg_with(32, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_neither"] = (dbg_with(3, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
 if want("encode"):
     for qw in (1, 2, 4):
