@@ -50,6 +50,9 @@ int svbgpu_device_ok(void);
 /* Tuning knobs (process-wide, not thread-safe against running calls):
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
  *                               encoder carries through the look-back (default 4)
+ *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
+ *                               streaming passes; 1: single pass with look-back
+ *   "debug_ablate" = bits       timing-only diagnostics, results become wrong
  * Results never depend on a knob, only speed. */
 int svbgpu_set_option(const char *name, int value);
 

@@ -126,6 +126,25 @@ void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, u
                      d_consumed);
 }
 
+int g_delta_lookback = 0;  // 1: single-pass look-back delta decoder, 0: two-pass (default)
+
+template <int V, bool ZZ>
+void launch_delta_decode2(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
+                          void* ws, uint64_t* d_consumed, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, 7);
+  u64* super_off = ws_at<u64>(ws, L.off_super_off);
+  u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
+  u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
+  u32* blk = ws_at<u32>(ws, L.off_blk);
+  const unsigned nblk = (unsigned)((L.n_wt + 1023) / 1024);
+  hipLaunchKernelGGL((k_value_sums<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, count, super_off, wt_rel, vsum);
+  hipLaunchKernelGGL(k_scan_u32_blocks, dim3(nblk), dim3(kBlock), 0, st, vsum, (u32)L.n_wt, blk);
+  hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, st, blk, nblk, prev);
+  hipLaunchKernelGGL((k_delta_decode2<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count, super_off,
+                     wt_rel, vsum, blk, d_consumed);
+}
+
 // decode with the directory already in the workspace
 int run_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
                uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st) {
@@ -136,13 +155,18 @@ int run_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out
               else    launch_decode<V1234, false>(d_in, d_out, count, ws, d_consumed, st); }
     else    { if (zz) launch_decode<V0124, true>(d_in, d_out, count, ws, d_consumed, st);
               else    launch_decode<V0124, false>(d_in, d_out, count, ws, d_consumed, st); }
-  } else {
+  } else if (g_delta_lookback) {
     int rc = clear_lookback(count, ws, st);
     if (rc) return rc;
     if (v0) { if (zz) launch_delta_decode<V1234, true>(d_in, d_out, count, prev, ws, d_consumed, st);
               else    launch_delta_decode<V1234, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
     else    { if (zz) launch_delta_decode<V0124, true>(d_in, d_out, count, prev, ws, d_consumed, st);
               else    launch_delta_decode<V0124, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
+  } else {
+    if (v0) { if (zz) launch_delta_decode2<V1234, true>(d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode2<V1234, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
+    else    { if (zz) launch_delta_decode2<V0124, true>(d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode2<V0124, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
   }
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
@@ -225,6 +249,10 @@ int svbgpu_set_option(const char* name, int value) {
   if (!name) return SVBGPU_EINVAL;
   if (!std::strcmp(name, "debug_ablate")) {
     g_debug = (unsigned)value;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "delta_decode_lookback")) {
+    g_delta_lookback = value != 0;
     return SVBGPU_OK;
   }
   if (!std::strcmp(name, "encode_tile")) {

@@ -121,6 +121,124 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Two-pass differential decode, no inter-workgroup waiting at all:
+//   k_value_sums     decode every wave tile once, keep only the sum of its values
+//   k_scan_u32_*     exclusive wrap-around scan of the 1024-value sums
+//   k_delta_decode2  decode again, add the wave tile's base, running sums, store
+// The stream is read twice (2*(0.25+dbar) + 4 bytes per value instead of
+// 0.25+dbar+4), which a streaming kernel at two thirds of HBM peak still turns
+// into less time than the look-back version's per-tile hand-off wait.
+template <int V, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_value_sums(const u8* __restrict__ in, u32 count,
+                                                       const u64* __restrict__ super_off,
+                                                       const u32* __restrict__ wt_rel,
+                                                       u32* __restrict__ wt_vsum) {
+  __shared__ WaveLds s_lds[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  WaveLds& S = s_lds[wave];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u32 stride = gridDim.x * kWaves;
+  const u8* data_base = in + keylen;
+  for (u32 wt = blockIdx.x * kWaves + wave; wt < n_wt; wt += stride) {
+    const u64 koff = (u64)wt * kWtKeys + 4 * lane;
+    const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
+    const u64 doff = super_off[wt / kSuperWt] + wt_rel[wt];
+    const u64 int0 = (u64)wt * kWtInts;
+    const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
+    uint4 v[4];
+    decode_wavetile<V, ZZ>(w, nints, data_base + doff, lane, S, v);
+    u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
+    s = wave_sum(s);
+    if (lane == 0) wt_vsum[wt] = s;
+  }
+}
+
+// In-place exclusive scan of `n` u32 in blocks of 1024 (4 per thread); block
+// totals to blk_tot[].  Second kernel: exclusive scan of the block totals by one
+// workgroup, seeded.  Wrap-around arithmetic throughout.
+__global__ __launch_bounds__(kBlock) void k_scan_u32_blocks(u32* __restrict__ a, u32 n,
+                                                            u32* __restrict__ blk_tot) {
+  __shared__ u32 s_w[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  const u32 i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+  u32 x[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = i0 + k < n ? a[i0 + k] : 0u;
+  const u32 t = x[0] + x[1] + x[2] + x[3];
+  const u32 incl = wave_scan_incl(t, lane);
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  u32 base = incl - t;
+  for (int w = 0; w < wave; ++w) base += s_w[w];
+  u32 run = base;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < n) a[i0 + k] = run;
+    run += x[k];
+  }
+  if (threadIdx.x == kBlock - 1) blk_tot[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(1024) void k_scan_u32_top(u32* __restrict__ blk, u32 n, u32 seed) {
+  __shared__ u32 s_w[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u32 per = (n + 1023) / 1024;
+  const u32 lo = min(n, t * per), hi = min(n, lo + per);
+  u32 mine = 0;
+  for (u32 i = lo; i < hi; ++i) mine += blk[i];
+  const u32 incl = wave_scan_incl(mine, lane);
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  u32 run = seed + incl - mine;
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+  for (u32 i = lo; i < hi; ++i) {
+    const u32 x = blk[i];
+    blk[i] = run;
+    run += x;
+  }
+}
+
+template <int V, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__ in,
+                                                          u32* __restrict__ out, u32 count,
+                                                          const u64* __restrict__ super_off,
+                                                          const u32* __restrict__ wt_rel,
+                                                          const u32* __restrict__ wt_vpre,
+                                                          const u32* __restrict__ blk_pre,
+                                                          u64* __restrict__ consumed) {
+  __shared__ WaveLds s_lds[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  WaveLds& S = s_lds[wave];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u32 stride = gridDim.x * kWaves;
+  const u8* data_base = in + keylen;
+  for (u32 wt = blockIdx.x * kWaves + wave; wt < n_wt; wt += stride) {
+    const u64 koff = (u64)wt * kWtKeys + 4 * lane;
+    const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
+    const u64 doff = super_off[wt / kSuperWt] + wt_rel[wt];
+    u32 run = wt_vpre[wt] + blk_pre[wt >> 10];  // sum of everything before this wave tile, incl. prev
+    const u64 int0 = (u64)wt * kWtInts;
+    const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
+    uint4 v[4];
+    const u32 total = decode_wavetile<V, ZZ>(w, nints, data_base + doff, lane, S, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 c = v[j];
+      c.y += c.x; c.z += c.y; c.w += c.z;
+      const u32 incl = wave_scan_incl(c.w, lane);
+      const u32 ex = incl - c.w + run;
+      run += wave_last(incl);
+      c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+      store_group(out, int0 + 4u * (j * 64 + lane), count, c);
+    }
+    if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;
+  }
+}
+
 // Plain inclusive running sum out[i] = seed + sum_{j<=i} f(in[j]), f = identity
 // or un-zigzag (zigzag_delta_decode).  8 B per value.
 template <bool ZZ>

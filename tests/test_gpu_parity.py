@@ -74,10 +74,13 @@ def test_delta_matches_oracle(torch_mod, codec, oracle, kind):
         codec.check()
         assert int(size.item()) == s.size
         assert np.array_equal(out[: s.size].cpu().numpy(), s), (kind, n)
-        dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA, prev=prev)
-        codec.check()
-        assert int(used.item()) == s.size
-        assert np.array_equal(to_np(dec, np.uint32), v), (kind, n)
+        for lookback in (0, 1):  # two-pass (default) and single-pass look-back decoders
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
+            dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA, prev=prev)
+            codec.check()
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+            assert int(used.item()) == s.size
+            assert np.array_equal(to_np(dec, np.uint32), v), (kind, n, lookback)
 
 
 def test_zigzag_fused_and_plain(torch_mod, codec, oracle):
@@ -111,6 +114,22 @@ def test_zigzag_fused_and_plain(torch_mod, codec, oracle):
         dec, used = codec.decode(dev_stream(torch_mod, expect), n, variant=V1234, flags=ZIGZAG | DELTA, prev=prev)
         codec.check()
         assert np.array_equal(to_np(dec, np.int32), g)
+
+
+def test_encoder_tile_sizes(torch_mod, codec, oracle):
+    """Every tile size of the encoder knob gives the same bytes."""
+    from streamvbyte_amd import DELTA
+    for i, n in enumerate([1, 4097, 16385, 65537, 262144 + 7, (1 << 20) + 3]):
+        v = gen("width_mix", n, 6000 + i)
+        for variant, flags, prev in ((V1234, 0, 0), (V0124, 0, 0), (V1234, DELTA, 99)):
+            expect = oracle.encode(variant, v, bool(flags), prev)
+            for qw in (1, 2, 4):
+                codec.lib.svbgpu_set_option(b"encode_tile", qw)
+                out, size = codec.encode(to_dev(torch_mod, v), variant=variant, flags=flags, prev=prev)
+                codec.check()
+                codec.lib.svbgpu_set_option(b"encode_tile", 4)
+                assert int(size.item()) == expect.size, (n, variant, flags, qw)
+                assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags, qw)
 
 
 def test_size_and_validate(torch_mod, codec, oracle):

@@ -78,6 +78,15 @@ if want("delta"):
     d3 = (int(z3.item()) - keylen) / n
     ops["delta_encode"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
     ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
+
+    def dd_lookback():
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+        codec.decode(s3, n, out=out, flags=svb.DELTA)
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+    ops["delta_decode_lookback"] = (dd_lookback, (4.25 + d3) * n)
+    sm, zm = codec.encode(values, flags=svb.DELTA)
+    sm = sm.clone()
+    ops["delta_decode_mixed"] = (lambda: codec.decode(sm, n, out=out, flags=svb.DELTA), (int(zm.item()) + 4.0 * n))
 if want("zz"):
     n4 = min(n, 1 << 26)
     g = torch.Generator(device=dev); g.manual_seed(9)
