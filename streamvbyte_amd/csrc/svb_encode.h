@@ -74,35 +74,66 @@ __device__ __forceinline__ u32 classify_group(const uint4& x, u32 nv) {
 // Concatenate the data bytes of a group: the low len[k] bytes of each value,
 // value 0 first, into 128 bits (d[0] = first four bytes).  Values must already
 // be < 256^len (true for every classified value; absent values are zero).
-__device__ __forceinline__ void pack_group(const uint4& x, u32 g, u32 (&d)[4]) {
+__device__ __forceinline__ uint4 pack_group(const uint4& x, u32 g) {
   const u32 b0 = gi_len(g, 0) * 8u, b1 = gi_len(g, 1) * 8u, b2 = gi_len(g, 2) * 8u;
   const u64 lo = (u64)x.x | ((u64)x.y << b0);  // b0 <= 32
   const u64 hi = (u64)x.z | ((u64)x.w << b2);
   const u32 s = b0 + b1;                       // 0..64 bits taken by values 0 and 1
   const u64 vlo = lo | (s < 64u ? hi << s : 0ull);
   const u64 vhi = s == 0u ? 0ull : (s < 64u ? hi >> (64u - s) : hi);
-  d[0] = (u32)vlo; d[1] = (u32)(vlo >> 32); d[2] = (u32)vhi; d[3] = (u32)(vhi >> 32);
+  return make_uint4((u32)vlo, (u32)(vlo >> 32), (u32)vhi, (u32)(vhi >> 32));
 }
 
-// Dword `i` (0..4) of the group's bytes once shifted to start at byte (p & 3)
+// Dword `I` (0..4) of the group's bytes once shifted to start at byte (p & 3)
 // of an aligned dword.
-__device__ __forceinline__ u32 shifted_dword(const u32 (&d)[4], int i, u32 a8) {
-  const u32 lo = i == 0 ? 0u : d[i - 1];
-  const u32 hi = i == 4 ? 0u : d[i];
-  return (u32)(((((u64)hi) << 32) | lo) << a8 >> 32);
+template <int I>
+__device__ __forceinline__ u32 shifted_dword(const uint4& d, u32 a8) {
+  const u32 lo = I == 0 ? 0u : (I == 1 ? d.x : (I == 2 ? d.y : (I == 3 ? d.z : d.w)));
+  const u32 hi = I == 0 ? d.x : (I == 1 ? d.y : (I == 2 ? d.z : (I == 3 ? d.w : 0u)));
+  // = ({hi,lo} << a8) >> 32, written with a funnel shift (a 64-bit value built from
+  // two adjacent vector elements makes hipcc spill the vector to scratch)
+  return a8 ? __builtin_amdgcn_alignbit(hi, lo, 32u - a8) : hi;
 }
 
 // 0124: OR the group's bytes into the zeroed LDS image at byte offset p.  An
 // image dword can be shared by several neighbouring groups (0124 groups can be
 // empty) whose bytes are disjoint, so an LDS atomic OR assembles it whatever
 // the order.
-__device__ __forceinline__ void or_into_image(u8* image, u32 p, u32 L, const u32 (&d)[4]) {
+__device__ __forceinline__ void or_into_image(u8* image, u32 p, u32 L, const uint4& d) {
   const u32 a8 = 8u * (p & 3u);
   u32* q = reinterpret_cast<u32*>(image + (p & ~3u));
   const u32 nd = (L + (p & 3u) + 3u) >> 2;  // dwords touched, 0..5
-#pragma unroll
-  for (int i = 0; i < 5; ++i)
-    if (nd > (u32)i) atomicOr(q + i, shifted_dword(d, i, a8));
+  if (nd > 0u) atomicOr(q + 0, shifted_dword<0>(d, a8));
+  if (nd > 1u) atomicOr(q + 1, shifted_dword<1>(d, a8));
+  if (nd > 2u) atomicOr(q + 2, shifted_dword<2>(d, a8));
+  if (nd > 3u) atomicOr(q + 3, shifted_dword<3>(d, a8));
+  if (nd > 4u) atomicOr(q + 4, shifted_dword<4>(d, a8));
+}
+
+// Store dword I of one group (1234 assembly, see encode_wavetile).
+template <int I, bool FULL>
+__device__ __forceinline__ void store_dword(u8* image, const uint4& d, u32 p, u32 g) {
+  const u32 L = gi_total(g);
+  const u32 nd = (FULL || L) ? (L + (p & 3u) + 3u) >> 2 : 0u;
+  u32* q = reinterpret_cast<u32*>(image + (p & ~3u));
+  if (nd > (u32)I) q[I] = shifted_dword<I>(d, 8u * (p & 3u));
+}
+template <int I, bool FULL>
+__device__ __forceinline__ void store_dword_all(u8* image, const uint4& d0, const uint4& d1,
+                                                const uint4& d2, const uint4& d3, u32 p0, u32 p1,
+                                                u32 p2, u32 p3, const u32 (&g)[4]) {
+  store_dword<I, FULL>(image, d0, p0, g[0]);
+  store_dword<I, FULL>(image, d1, p1, g[1]);
+  store_dword<I, FULL>(image, d2, p2, g[2]);
+  store_dword<I, FULL>(image, d3, p3, g[3]);
+}
+template <bool FULL>
+__device__ __forceinline__ void store_head(u8* image, const uint4& d, u32 p, u32 g) {
+  if (FULL || gi_total(g)) {
+    image[p] = (u8)d.x;
+    image[p + 1] = (u8)(d.x >> 8);
+    image[p + 2] = (u8)(d.x >> 16);
+  }
 }
 
 // One wave tile, values -> bytes.  x[j] holds group j*64+lane (already delta /
@@ -126,17 +157,14 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&
   const u32 t0 = (u32)(tots & 0xFFFFu), t1 = (u32)((tots >> 16) & 0xFFFFu),
             t2 = (u32)((tots >> 32) & 0xFFFFu), t3 = (u32)(tots >> 48);
   const u32 total = t0 + t1 + t2 + t3;
-  u32 p[4];
-  p[0] = a + (u32)(excl & 0xFFFFu);
-  p[1] = a + t0 + (u32)((excl >> 16) & 0xFFFFu);
-  p[2] = a + t0 + t1 + (u32)((excl >> 32) & 0xFFFFu);
-  p[3] = a + t0 + t1 + t2 + (u32)(excl >> 48);
-  u32 d[4][4];
+  const u32 p0 = a + (u32)(excl & 0xFFFFu);
+  const u32 p1 = a + t0 + (u32)((excl >> 16) & 0xFFFFu);
+  const u32 p2 = a + t0 + t1 + (u32)((excl >> 32) & 0xFFFFu);
+  const u32 p3 = a + t0 + t1 + t2 + (u32)(excl >> 48);
+  const uint4 d0 = pack_group(x[0], g[0]), d1 = pack_group(x[1], g[1]), d2 = pack_group(x[2], g[2]),
+              d3 = pack_group(x[3], g[3]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    pack_group(x[j], g[j], d[j]);
-    S.keys[j * 64 + lane] = (u8)gi_key(g[j]);
-  }
+  for (int j = 0; j < 4; ++j) S.keys[j * 64 + lane] = (u8)gi_key(g[j]);
 
   if (V == V1234) {
     // Plain aligned dword stores, no atomics.  A dword on the border of two
@@ -149,30 +177,24 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&
     // lane for its own group (the first three bytes of a 1234 group always
     // exist).  LDS executes one wave's stores in program order.  Groups without
     // bytes (past the end of the stream) store nothing.
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32 L = gi_total(g[j]);
-        const u32 nd = (FULL || L) ? (L + (p[j] & 3u) + 3u) >> 2 : 0u;
-        u32* q = reinterpret_cast<u32*>(S.data + (p[j] & ~3u));
-        if (nd > (u32)i) q[i] = shifted_dword(d[j], i, 8u * (p[j] & 3u));
-      }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (FULL || gi_total(g[j])) {
-        S.data[p[j]] = (u8)d[j][0];
-        S.data[p[j] + 1] = (u8)(d[j][0] >> 8);
-        S.data[p[j] + 2] = (u8)(d[j][0] >> 16);
-      }
-    }
+    store_dword_all<0, FULL>(S.data, d0, d1, d2, d3, p0, p1, p2, p3, g);
+    store_dword_all<1, FULL>(S.data, d0, d1, d2, d3, p0, p1, p2, p3, g);
+    store_dword_all<2, FULL>(S.data, d0, d1, d2, d3, p0, p1, p2, p3, g);
+    store_dword_all<3, FULL>(S.data, d0, d1, d2, d3, p0, p1, p2, p3, g);
+    store_dword_all<4, FULL>(S.data, d0, d1, d2, d3, p0, p1, p2, p3, g);
+    store_head<FULL>(S.data, d0, p0, g[0]);
+    store_head<FULL>(S.data, d1, p1, g[1]);
+    store_head<FULL>(S.data, d2, p2, g[2]);
+    store_head<FULL>(S.data, d3, p3, g[3]);
   } else {
     // zero the image: [0, a+total) rounded up to whole 16-byte chunks
     const u32 nz = (a + total + 15u) >> 4;  // <= 258
     uint4* l16 = reinterpret_cast<uint4*>(S.data);
     for (u32 c = lane; c < nz; c += 64) l16[c] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) or_into_image(S.data, p[j], gi_total(g[j]), d[j]);
+    or_into_image(S.data, p0, gi_total(g[0]), d0);
+    or_into_image(S.data, p1, gi_total(g[1]), d1);
+    or_into_image(S.data, p2, gi_total(g[2]), d2);
+    or_into_image(S.data, p3, gi_total(g[3]), d3);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
