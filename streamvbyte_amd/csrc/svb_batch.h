@@ -10,19 +10,22 @@
 #include "svb_decode.h"
 #include "svb_encode.h"
 
+#include <algorithm>
+
 namespace svb {
 
 template <int V, bool DELTA, bool ZZ>
 __global__ __launch_bounds__(kBlock) void k_decode_batch(
     const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
     const u64* __restrict__ value_off, const u32* __restrict__ counts,
-    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes) {
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 min_count) {
   __shared__ WaveLds s_lds[kWaves];
   const int lane = lane_id(), wave = wave_id();
   WaveLds& S = s_lds[wave];
   const u32 stride = gridDim.x * kWaves;
   for (u32 s = blockIdx.x * kWaves + wave; s < nstreams; s += stride) {
     const u32 count = counts[s];
+    if (count < min_count) continue;  // short lists belong to k_decode_batch_rows
     const u8* in = bytes + byte_off[s];
     u32* out = values + value_off[s];
     const u64 keylen = ((u64)count + 3) >> 2;
@@ -50,6 +53,91 @@ __global__ __launch_bounds__(kBlock) void k_decode_batch(
       }
     }
     if (sizes && lane == 0) sizes[s] = count ? keylen + doff : 0;
+  }
+}
+
+// Short lists: one list per ROW of 16 lanes (four lists per wavefront at a time),
+// one group per lane and step, no LDS at all.  A lane reads its key byte, a row
+// scan (DPP row_shr) of the group lengths gives its data offset, the group's
+// <= 16 data bytes come in with one 16-byte load at their own byte address
+// (neighbouring lanes hit the same cache lines; the over-read stays inside the
+// stream's 16-byte padding) and the four values are cut out of that register
+// quad.  Handles lists of 1..kRowMax values; longer ones loop in steps of 64.
+constexpr u32 kRowMax = 256;
+
+__device__ __forceinline__ u32 row_scan_incl(u32 x) {
+  x += dpp_zero<0x111, 0xF>(x);
+  x += dpp_zero<0x112, 0xF>(x);
+  x += dpp_zero<0x114, 0xF>(x);
+  x += dpp_zero<0x118, 0xF>(x);
+  return x;
+}
+// value of lane 15 of the caller's row
+__device__ __forceinline__ u32 row_last(u32 x, int lane) { return __shfl(x, (lane & 48) | 15, 64); }
+
+// bytes [o, o+4) of the 16-byte little-endian value d (o = 0..12), zero beyond
+__device__ __forceinline__ u32 bytes_at(const uint4& d, u32 o) {
+  const u32 i = o >> 2;
+  const u32 lo = i == 0 ? d.x : (i == 1 ? d.y : (i == 2 ? d.z : d.w));
+  const u32 hi = i == 0 ? d.y : (i == 1 ? d.z : (i == 2 ? d.w : 0u));
+  return __builtin_amdgcn_alignbyte(hi, lo, o);
+}
+
+template <int V, bool DELTA, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_decode_batch_rows(
+    const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
+    const u64* __restrict__ value_off, const u32* __restrict__ counts,
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes) {
+  const int lane = lane_id();
+  const int lr = lane & 15;
+  const u32 nrows = gridDim.x * (kBlock / 16);
+  for (u32 s = blockIdx.x * (kBlock / 16) + (threadIdx.x >> 4); s < nstreams; s += nrows) {
+    const u32 count = counts[s];
+    if (count == 0) {
+      if (sizes && lr == 0) sizes[s] = 0;
+      continue;
+    }
+    if (count > kRowMax) continue;  // k_decode_batch takes the long lists
+    const u8* in = bytes + byte_off[s];
+    u32* out = values + value_off[s];
+    const u32 keylen = (count + 3) >> 2;
+    const u8* data = in + keylen;
+    u32 doff = 0;
+    u32 run = (DELTA && prevs) ? prevs[s] : 0u;
+    for (u32 g0 = 0; g0 < keylen; g0 += 16) {
+      const u32 g = g0 + lr;
+      const bool have = g < keylen;
+      u32 key = have ? in[g] : 0u;
+      const u32 nv = have ? min(4u, count - 4u * g) : 0u;
+      key &= nv >= 4u ? 0xFFu : ((1u << (2u * nv)) - 1u);
+      u32 l[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) l[k] = (u32)k < nv ? len_of<V>((key >> (2 * k)) & 3u) : 0u;
+      const u32 L = l[0] + l[1] + l[2] + l[3];
+      const u32 incl = row_scan_incl(L);
+      const u32 off = doff + incl - L;
+      doff += row_last(incl, lane);
+      uint4 d = make_uint4(0, 0, 0, 0);
+      if (have) d = ld_u128(data + off);
+      uint4 c;
+      c.x = bytes_at(d, 0) & (l[0] ? mask_of<V>(key & 3u) : 0u);
+      c.y = bytes_at(d, l[0]) & (l[1] ? mask_of<V>((key >> 2) & 3u) : 0u);
+      c.z = bytes_at(d, l[0] + l[1]) & (l[2] ? mask_of<V>((key >> 4) & 3u) : 0u);
+      c.w = bytes_at(d, l[0] + l[1] + l[2]) & (l[3] ? mask_of<V>((key >> 6) & 3u) : 0u);
+      if (ZZ) {
+        c = make_uint4(zz_dec(c.x), zz_dec(c.y), zz_dec(c.z), zz_dec(c.w));
+        if (nv < 4u) { c.w = 0; if (nv < 3u) c.z = 0; if (nv < 2u) c.y = 0; if (nv < 1u) c.x = 0; }
+      }
+      if (DELTA) {
+        c.y += c.x; c.z += c.y; c.w += c.z;
+        const u32 si = row_scan_incl(c.w);
+        const u32 ex = si - c.w + run;
+        run += row_last(si, lane);
+        c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+      }
+      if (have) store_group(out, 4u * g, count, c);
+    }
+    if (sizes && lr == 0) sizes[s] = (u64)keylen + doff;
   }
 }
 
@@ -102,8 +190,12 @@ void launch_decode_batch(unsigned grid, const uint8_t* d_bytes, const uint64_t* 
                          uint32_t* d_values, const uint64_t* d_value_off, const uint32_t* d_counts,
                          const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes,
                          hipStream_t st) {
+  // short lists, four to a wavefront; then the long ones, one wavefront each
+  const unsigned rows_grid = (unsigned)std::min<unsigned long long>(grid, ((unsigned long long)nstreams + 15) / 16);
+  hipLaunchKernelGGL((k_decode_batch_rows<V, D, Z>), dim3(rows_grid ? rows_grid : 1), dim3(kBlock), 0, st,
+                     d_bytes, d_byte_off, d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes);
   hipLaunchKernelGGL((k_decode_batch<V, D, Z>), dim3(grid), dim3(kBlock), 0, st, d_bytes, d_byte_off,
-                     d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes);
+                     d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes, kRowMax + 1);
 }
 template <int V, bool D, bool Z>
 void launch_encode_batch(unsigned grid, const uint32_t* d_values, const uint64_t* d_value_off,
