@@ -189,10 +189,10 @@ void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint
   u64* stamps = (g_debug & 16u) && g_ws_bytes_hint >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
   if (full_tiles)
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true>), dim3(full_tiles), dim3(kBlock), 0, st, d_in, count,
-                       d_out, prev, h, status, d_written, g_debug, stamps);
-  if (ragged)  // the one tile that runs past the end of the stream: same ticket, same look-back words
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false>), dim3(1), dim3(kBlock), 0, st, d_in, count,
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true>), dim3(stream_grid(full_tiles, QW > 2 || V != V1234 ? 4 : 5)), dim3(kBlock),
+                       0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, g_debug, stamps);
+  if (ragged)  // the one tile that runs past the end of the stream: same look-back words
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false>), dim3(1), dim3(kBlock), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, g_debug, stamps);
 }
 template <int V, bool D, bool Z>

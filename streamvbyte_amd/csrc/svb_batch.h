@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_encode_batch(
         const u64 first = int0 + 4u * (j * 64 + lane);
         if (DELTA || ZZ) zero_absent(c, first, count);
         x[j] = c;
-        g[j] = classify_group<V>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
+        g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
       }
       doff += encode_wavetile<V, false>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
     }

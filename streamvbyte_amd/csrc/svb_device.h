@@ -84,10 +84,11 @@ __device__ __forceinline__ u32 wave_shift_up1(u32 x, u32 first) {
   return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xF, 0xF, false);  // wave_shr:1
 }
 __device__ __forceinline__ u32 wave_sum(u32 x) { return wave_last(wave_scan_incl(x, 0)); }
+// 64-bit sum over the wavefront as three 32-bit DPP reductions of 26-bit pieces
+// (a chain of twelve ds_bpermute shuffles costs several hundred cycles).
 __device__ __forceinline__ u64 wave_sum64(u64 x) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
-  return x;
+  const u32 a = (u32)x & 0x3FFFFFFu, b = (u32)(x >> 26) & 0x3FFFFFFu, c = (u32)(x >> 52);
+  return (u64)wave_sum(a) + ((u64)wave_sum(b) << 26) + ((u64)wave_sum(c) << 52);
 }
 
 // ---- width arithmetic -------------------------------------------------------

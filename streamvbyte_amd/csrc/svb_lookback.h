@@ -31,7 +31,7 @@ __device__ __forceinline__ void lb_publish(u64* status, u32 tile, u64 flag, u64 
 template <int kLbWin = 4>  // status words polled per lane and round (window = 64 * kLbWin tiles)
 __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, int lane,
                                                    u32* err, u32* rounds_out = nullptr) {
-  u64 prefix = 0;
+  u64 mine = 0;                          // this lane's share of the sum, reduced once at the end
   long long base = (long long)tile - 1;  // nearest predecessor not yet summed
   u32 spins = 0, rounds = 0;
   while (true) {
@@ -45,7 +45,6 @@ __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, 
         s[i] = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bool done = false, stall = false;
-    u64 add = 0;
 #pragma unroll
     for (int i = 0; i < kLbWin; ++i) {
       if (!done && !stall) {
@@ -57,13 +56,12 @@ __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, 
         if (inv & need) {
           stall = true;  // a word we need is not published yet
         } else {
-          add += wave_sum64(lane <= first ? (s[i] & kLbVal) : 0ull);
+          if (lane <= first) mine += s[i] & kLbVal;
           if (first < 64) done = true;
           else base -= 64;
         }
       }
     }
-    prefix += add;
     if (done) break;
     if (stall) {
       __builtin_amdgcn_s_sleep(2);
@@ -73,6 +71,7 @@ __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, 
       }
     }
   }
+  const u64 prefix = wave_sum64(mine);
   if (rounds_out) *rounds_out = rounds;
   return prefix;
 }

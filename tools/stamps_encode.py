@@ -36,6 +36,21 @@ r = st[1:, 4]
 print("poll rounds: mean %.2f p50 %.0f p90 %.0f max %.0f; lookback us per round p50 %.2f" % (r.mean(), np.percentile(r,50), np.percentile(r,90), r.max(), np.percentile((resolved-loaded)[1:]/np.maximum(r,1),50)))
 print("resolve(i) - resolve(i-1): p50 %.3f p90 %.3f us" % (np.percentile(np.diff(resolved), 50), np.percentile(np.diff(resolved), 90)))
 print("resolved - max(loaded(i), loaded(i-1)): p50 %.2f p90 %.2f us" % tuple(np.percentile(resolved[1:] - np.maximum(loaded[1:], loaded[:-1]), [50, 90])))
+# the earliest a tile could resolve whatever the protocol: when the last of its predecessors has published
+runmax = np.maximum.accumulate(loaded)
+inherent = np.maximum(runmax[:-1] - loaded[1:], 0.0)
+actual = (resolved - loaded)[1:]
+print("inherent wait (max predecessor publish - own publish): mean %.2f p50 %.2f p90 %.2f us" % (inherent.mean(), *np.percentile(inherent, [50, 90])))
+print("protocol overhead (actual - inherent): mean %.2f p50 %.2f p90 %.2f us" % ((actual - inherent).mean(), *np.percentile(actual - inherent, [50, 90])))
+print("tiles started per us (steady state): %.1f" % ((tiles // 2) / (start[3 * tiles // 4] - start[tiles // 4])))
+# occupancy of the phases over time (2 us bins over the middle of the run): a convoy shows as
+# the three counts swinging in turn instead of staying level
+t_lo, t_hi = done.max() * 0.4, done.max() * 0.4 + 80
+print("   t_us  loading waiting writing  starts")
+for b in np.arange(t_lo, t_hi, 2.0):
+    mid = b + 1.0
+    print(f"{b:7.0f} {int(((start <= mid) & (mid < loaded)).sum()):8d} {int(((loaded <= mid) & (mid < resolved)).sum()):7d} "
+          f"{int(((resolved <= mid) & (mid < done)).sum()):7d} {int(((start >= b) & (start < b + 2)).sum()):7d}")
 for lo in (0, tiles // 2, tiles - 12):
     print("tile start loaded resolved done")
     for i in range(lo, min(lo + 10, tiles)):
