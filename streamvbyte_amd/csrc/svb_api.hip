@@ -205,7 +205,7 @@ void launch_encode(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_
 template <int V, bool D, bool Z>
 void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* d_bytes,
                  hipStream_t st) {
-  const unsigned grid = stream_grid(((unsigned long long)count / 4 + kBlock - 1) / kBlock / 4 + 1, 8);
+  const unsigned grid = stream_grid(((unsigned long long)count / 4 + kBlock - 1) / kBlock / 4 + 1, 4);
   hipLaunchKernelGGL((k_size<V, D, Z>), dim3(grid), dim3(kBlock), 0, st, d_in, count, prev, d_bytes);
 }
 
@@ -352,17 +352,22 @@ int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   if (!ws || ws_bytes < sizeof(WsHeader) || ((uintptr_t)ws & 255u)) return SVBGPU_EWORKSPACE;
   const u64 keylen = ((u64)count + 3) >> 2;
-  u64* accum = &ws_hdr(ws)->accum;
-  HIP_TRY(hipMemsetAsync(accum, 0, 8, S(stream)));
-  if (in_length != 0 && count != 0 && keylen <= in_length) {
-    if (!d_in) return SVBGPU_EINVAL;
-    const unsigned grid = stream_grid(((keylen + 15) / 16 + kBlock - 1) / kBlock, 8);
-    if (variant == SVBGPU_1234)
-      hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count, accum);
-    else
-      hipLaunchKernelGGL(k_validate_sum<V0124>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count, accum);
+  if (in_length == 0 || count == 0 || keylen > in_length) {
+    // nothing to sum (reference src/streamvbyte_decode.c:91-111): the answer is known here
+    const int r = (in_length == 0 || count == 0) ? in_length == (u64)count : 0;
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_ok), r, 1, S(stream)));
+    return SVBGPU_OK;
   }
-  hipLaunchKernelGGL(k_validate_finish, dim3(1), dim3(64), 0, S(stream), accum, (u64)in_length, count, d_ok);
+  if (!d_in) return SVBGPU_EINVAL;
+  WsHeader* h = ws_hdr(ws);
+  HIP_TRY(hipMemsetAsync(&h->accum, 0, 8, S(stream)));
+  const unsigned grid = stream_grid(((keylen + 15) / 16 + kBlock - 1) / kBlock, 2);
+  if (variant == SVBGPU_1234)
+    hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count,
+                       (u64)in_length, &h->accum, d_ok);
+  else
+    hipLaunchKernelGGL(k_validate_sum<V0124>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count,
+                       (u64)in_length, &h->accum, d_ok);
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

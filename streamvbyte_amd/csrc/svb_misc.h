@@ -61,11 +61,14 @@ __global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32
 // ---------------------------------------------------------------------------
 // k_validate_sum: data bytes promised by the first `count` codes of the key
 // block (reference src/streamvbyte_decode.c:113-133,
-// src/streamvbyte_0124_decode.c:206-226).  *accum must be zero before launch.
+// src/streamvbyte_0124_decode.c:206-226) and, in the workgroup that finishes
+// last, the final comparison with inLength (src/streamvbyte_decode.c:134-135).
+// *accum must be zero before launch; in_length >= keyLen > 0.
 // Reads 0.25 B per value.
 template <int V>
 __global__ __launch_bounds__(kBlock) void k_validate_sum(const u8* __restrict__ in, u32 count,
-                                                         u64* __restrict__ accum) {
+                                                         u64 in_length, u64* __restrict__ accum,
+                                                         u32* __restrict__ ok) {
   __shared__ u64 s_tmp[kWaves];
   const u64 keylen = ((u64)count + 3) >> 2;
   const u64 nchunks = (keylen + 15) >> 4;
@@ -90,23 +93,13 @@ __global__ __launch_bounds__(kBlock) void k_validate_sum(const u8* __restrict__ 
     }
   }
   const u64 tot = block_sum64(acc, s_tmp);
-  if (threadIdx.x == 0 && tot)
-    atomicAdd(reinterpret_cast<unsigned long long*>(accum), (unsigned long long)tot);
-}
-
-// Final comparison of streamvbyte_validate_stream (reference
-// src/streamvbyte_decode.c:91-102,135).
-__global__ void k_validate_finish(const u64* __restrict__ accum, u64 in_length, u32 count,
-                                  u32* __restrict__ ok) {
-  if (threadIdx.x || blockIdx.x) return;
-  u32 r;
-  if (in_length == 0 || count == 0) {
-    r = in_length == (u64)count;
-  } else {
-    const u64 keylen = ((u64)count + 3) >> 2;
-    r = keylen <= in_length && *accum == in_length - keylen;
+  if (threadIdx.x == 0) {
+    // one atomic per workgroup carries its sum (low 48 bits; a stream holds < 2^35
+    // data bytes) and counts it in (high 16 bits; the grid has < 2^16 workgroups)
+    const u64 old = atomicAdd(reinterpret_cast<unsigned long long*>(accum), (unsigned long long)(tot | (1ull << 48)));
+    if ((old >> 48) == gridDim.x - 1)  // every other workgroup's sum is in
+      *ok = ((old & ((1ull << 48) - 1)) + tot) == in_length - keylen;
   }
-  *ok = r;
 }
 
 // ---------------------------------------------------------------------------
