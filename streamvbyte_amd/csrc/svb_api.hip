@@ -184,7 +184,7 @@ void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint
   const unsigned full_tiles = (unsigned)(count / kTileInts);
   const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
   WsHeader* h = ws_hdr(ws);
-  u64* status = ws_at<u64>(ws, L.off_status);
+  const LbWords status{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
   u64* stamps = (g_debug & 16u) && g_ws_bytes_hint >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;

@@ -174,7 +174,7 @@ static_assert(sizeof(WsHeader) == 256, "header is one 256-byte block");
 
 struct WsLayout {
   u64 n_wt, n_super, n_tiles;
-  size_t off_super_off, off_wt_rel, off_super_sum, off_status, off_wt_vsum, off_blk, total;
+  size_t off_super_off, off_wt_rel, off_super_sum, off_status, off_lb_group, off_wt_vsum, off_blk, total;
 };
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kLbWt = 16;  // wave tiles per look-back tile (16384 values)
@@ -188,6 +188,7 @@ __host__ __device__ inline WsLayout ws_layout(u32 count) {
   size_t o = sizeof(WsHeader);
   // the look-back words follow the header so one memset clears both
   L.off_status = o;    o += align256(8 * (L.n_wt / kWaves + 2));  // room for the smallest tile size
+  L.off_lb_group = o;  o += align256(8 * (L.n_wt / kWaves / 16 + 2));  // group words of the two-level look-back
   L.off_super_off = o; o += align256(8 * (L.n_super + 1));
   L.off_wt_rel = o;    o += align256(4 * L.n_wt);
   L.off_super_sum = o; o += align256(4 * L.n_super);

@@ -98,6 +98,25 @@ __device__ __forceinline__ u32 classify_group(const uint4& x, u32 nv) {
   return g;
 }
 
+// Key byte alone of a group of four present values (what classify_group puts in
+// bits 7..0).
+template <int V>
+__device__ __forceinline__ u32 classify_key(const uint4& x) {
+  const u32 v[4] = {x.x, x.y, x.z, x.w};
+  u32 key = 0;
+  if (V == V1234) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) key |= ((ffbh_raw(v[k]) >> 3) & 3u) << (2 * k);
+    return key ^ 0xFFu;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = (int)((ffbh_raw(v[k]) >> 3) & 7u);
+    key |= (u32)min(max(4 - t, 0), 3) << (2 * k);
+  }
+  return key;
+}
+
 // Concatenate the data bytes of a group: the low len[k] bytes of each value,
 // value 0 first, into 128 bits (d.x = first four bytes).  Values must already
 // be < 256^len (true for every classified value; absent values are zero, and
@@ -162,21 +181,12 @@ __device__ __forceinline__ void store_dword(const GroupSlot& s, const uint4& d) 
   const u32 v = shifted_dword<I>(d, s.sel);
   if ((FULL && I == 0) || s.e > 4u * I) s.q[I] = v;
 }
-template <int I, bool FULL>
-__device__ __forceinline__ void store_dword_all(const GroupSlot& s0, const GroupSlot& s1, const GroupSlot& s2,
-                                                const GroupSlot& s3, const uint4& d0, const uint4& d1,
-                                                const uint4& d2, const uint4& d3) {
-  store_dword<I, FULL>(s0, d0);
-  store_dword<I, FULL>(s1, d1);
-  store_dword<I, FULL>(s2, d2);
-  store_dword<I, FULL>(s3, d3);
-}
 template <bool FULL>
-__device__ __forceinline__ void store_head(u8* image, const uint4& d, u32 p, u32 g) {
+__device__ __forceinline__ void store_head(u8* image, u32 first_dword, u32 p, u32 g) {
   if (FULL || gi_total(g)) {
-    image[p] = (u8)d.x;
-    image[p + 1] = (u8)(d.x >> 8);
-    image[p + 2] = (u8)(d.x >> 16);
+    image[p] = (u8)first_dword;
+    image[p + 1] = (u8)(first_dword >> 8);
+    image[p + 2] = (u8)(first_dword >> 16);
   }
 }
 
@@ -205,42 +215,48 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&
   const u32 p1 = a + t0 + (u32)((excl >> 16) & 0xFFFFu);
   const u32 p2 = a + t0 + t1 + (u32)((excl >> 32) & 0xFFFFu);
   const u32 p3 = a + t0 + t1 + t2 + (u32)(excl >> 48);
-  const uint4 d0 = pack_group<V>(x[0], g[0]), d1 = pack_group<V>(x[1], g[1]), d2 = pack_group<V>(x[2], g[2]),
-              d3 = pack_group<V>(x[3], g[3]);
 #pragma unroll
   for (int j = 0; j < 4; ++j) S.keys[j * 64 + lane] = (u8)gi_key(g[j]);
+  const u32 pj[4] = {p0, p1, p2, p3};
 
   if (V == V1234) {
     // Plain aligned dword stores, no atomics.  A dword on the border of two
     // groups is written by both (1234 groups have >= 4 bytes, so never by
     // three): by the later group as its dword 0, by the earlier one as its last
-    // dword, index >= 1.  Stores are issued dword index by dword index over all
-    // four quarters, so the earlier group's store lands last and the border
-    // dword ends up with its tail bytes and zeros where the later group's first
-    // 1..3 bytes belong.  Those are then written again, byte by byte, by every
-    // lane for its own group (the first three bytes of a 1234 group always
-    // exist).  LDS executes one wave's stores in program order.  Groups without
-    // bytes (past the end of the stream) store nothing.
-    const GroupSlot s0 = group_slot<FULL>(S.data, p0, g[0]), s1 = group_slot<FULL>(S.data, p1, g[1]),
-                    s2 = group_slot<FULL>(S.data, p2, g[2]), s3 = group_slot<FULL>(S.data, p3, g[3]);
-    store_dword_all<0, FULL>(s0, s1, s2, s3, d0, d1, d2, d3);
-    store_dword_all<1, FULL>(s0, s1, s2, s3, d0, d1, d2, d3);
-    store_dword_all<2, FULL>(s0, s1, s2, s3, d0, d1, d2, d3);
-    store_dword_all<3, FULL>(s0, s1, s2, s3, d0, d1, d2, d3);
-    store_dword_all<4, FULL>(s0, s1, s2, s3, d0, d1, d2, d3);
-    store_head<FULL>(S.data, d0, p0, g[0]);
-    store_head<FULL>(S.data, d1, p1, g[1]);
-    store_head<FULL>(S.data, d2, p2, g[2]);
-    store_head<FULL>(S.data, d3, p3, g[3]);
+    // dword, index >= 1.  The quarters are stored last first, and inside a
+    // quarter dword index by dword index, so the earlier group's store always
+    // lands after the later group's dword 0 (LDS executes one wave's stores in
+    // program order): the border dword ends up with the earlier group's tail
+    // bytes and zeros where the later group's first 1..3 bytes belong.  Those
+    // are written again at the end, byte by byte, by every lane for its own
+    // groups (the first three bytes of a 1234 group always exist).  Groups
+    // without bytes (past the end of the stream) store nothing.  One quarter at
+    // a time keeps only one packed group per lane live.
+    u32 head[4];
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+      const uint4 d = pack_group<V>(x[j], g[j]);
+      const GroupSlot s = group_slot<FULL>(S.data, pj[j], g[j]);
+      store_dword<0, FULL>(s, d);
+      store_dword<1, FULL>(s, d);
+      store_dword<2, FULL>(s, d);
+      store_dword<3, FULL>(s, d);
+      store_dword<4, FULL>(s, d);
+      head[j] = d.x;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_head<FULL>(S.data, head[j], pj[j], g[j]);
   } else {
     // zero the image: [0, a+total) rounded up to whole 16-byte chunks
     const u32 nz = (a + total + 15u) >> 4;  // <= 258
     uint4* l16 = reinterpret_cast<uint4*>(S.data);
     for (u32 c = lane; c < nz; c += 64) l16[c] = make_uint4(0, 0, 0, 0);
-    or_into_image(S.data, p0, gi_total(g[0]), d0);
-    or_into_image(S.data, p1, gi_total(g[1]), d1);
-    or_into_image(S.data, p2, gi_total(g[2]), d2);
-    or_into_image(S.data, p3, gi_total(g[3]), d3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      or_into_image(S.data, pj[j], gi_total(g[j]), pack_group<V>(x[j], g[j]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -297,7 +313,7 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 template <int V, bool DELTA, bool ZZ, int QW, bool FULL>
 __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
-    WsHeader* __restrict__ hdr, u64* __restrict__ status, u64* __restrict__ written, u32 dbg,
+    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
     u64* __restrict__ stamps) {
   __shared__ EncWaveLds s_lds[kWaves];
   __shared__ u32 s_wave_tot[kWaves];
@@ -325,7 +341,8 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
 
   // ---- pass 1: load, transform, classify -----------------------------------
   uint4 x[QW][4];
-  u32 g[QW][4];
+  u32 g[QW][4];  // !FULL: one descriptor per group
+  u32 kq[QW];    // FULL: the four key bytes of a wave tile in one register (lengths follow from them)
   if (FULL) {
     const uint4* src = reinterpret_cast<const uint4*>(in + wave_first);  // wave-uniform base + lane offset
 #pragma unroll
@@ -371,9 +388,21 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
         if (DELTA || ZZ) zero_absent(c, first, count);
         nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
       }
-      g[q][j] = classify_group<V, FULL>(c, nv);
-      lane_tot += gi_total(g[q][j]);
+      if (!FULL) {
+        g[q][j] = classify_group<V, false>(c, nv);
+        lane_tot += gi_total(g[q][j]);
+      }
     }
+  if (FULL) {
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      u32 k4 = classify_key<V>(x[q][0]) | (classify_key<V>(x[q][1]) << 8) | (classify_key<V>(x[q][2]) << 16) |
+               (classify_key<V>(x[q][3]) << 24);
+      asm volatile("" : "+v"(k4));  // keep the four keys in ONE register from here on
+      kq[q] = k4;
+      lane_tot += word_len<V>(k4, 16u);
+    }
+  }
   const u32 wave_tot = wave_sum(lane_tot);
   if (lane == 0) s_wave_tot[wave] = wave_tot;
   __syncthreads();
@@ -383,17 +412,17 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
   if (wave == 0) {
     const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
     u64 excl = 0;
-    if (tile == 0) {
-      if (lane == 0) lb_publish(status, 0, kLbPfx, tile_tot);
+    u32 rounds = 0;
+    if (!(dbg & 1u)) {
+      excl = lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error, &rounds);
     } else {
-      if (lane == 0) lb_publish(status, tile, kLbAgg, tile_tot);
-      // smaller tiles are drawn faster, so the window widens with 1/QW (256 .. 1024 tiles)
-      u32 rounds = 0;
-      if (!(dbg & 1u)) excl = lb_exclusive_prefix<16 / QW>(status, tile, lane, &hdr->error, &rounds);
-      else excl = (u64)tile * (kTileInts * 5 / 2);  // timing experiment: no wait, plausible (wrong) offsets
-      if (stamps && lane == 0) stamps[5 * (u64)tile + 4] = rounds;
-      if (lane == 0) lb_publish(status, tile, kLbPfx, excl + tile_tot);
+      excl = (u64)tile * (kTileInts * 5 / 2);  // timing experiment: no look-back, plausible (wrong) offsets
+      if (dbg & 4u) {                          // ... after idling about as long as a look-back takes
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < 1100) __builtin_amdgcn_s_sleep(16);
+      }
     }
+    if (stamps && lane == 0) stamps[5 * (u64)tile + 4] = rounds;
     if (stamps && lane == 0) stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       s_prefix = excl;
@@ -417,18 +446,24 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
   for (int q = 0; q < QW; ++q) {
     const u64 wt_first = wave_first + (u64)q * kWtInts;
     if (FULL) {
-      doff += encode_wavetile<V, true>(x[0], g[0], kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
+      const u32 lens4 = key_lens4<V>(kq[0], 16u);
+      u32 gq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gq[j] = ((kq[0] >> (8 * j)) & 0xFFu) | (((lens4 >> (8 * j)) & 0xFFu) << 24);
+      doff += encode_wavetile<V, true>(x[0], gq, kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
     } else if (wt_first < count) {
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - wt_first);
       doff += encode_wavetile<V, false>(x[0], g[0], nints, lane, S, data_out + doff, out + (wt_first >> 2));
     }
 #pragma unroll
-    for (int r = 0; r + 1 < QW; ++r)
+    for (int r = 0; r + 1 < QW; ++r) {
+      kq[r] = kq[r + 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         x[r][j] = x[r + 1][j];
         g[r][j] = g[r + 1][j];
       }
+    }
   }
   }
   if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 3] = __builtin_amdgcn_s_memrealtime();
