@@ -122,8 +122,8 @@ void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, u
   const WsLayout L = ws_layout(count);
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
                      d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
-                     ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws), ws_at<u64>(ws, L.off_status),
-                     d_consumed);
+                     ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
+                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
 }
 
 int g_delta_lookback = 0;  // 1: single-pass look-back delta decoder, 0: two-pass (default)
@@ -406,9 +406,9 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   rc = clear_lookback(count, ws, S(stream));
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
-  hipLaunchKernelGGL(k_running_sum<true>, dim3((unsigned)L.n_tiles), dim3(kBlock), 0, S(stream), d_in,
-                     reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, ws_hdr(ws),
-                     ws_at<u64>(ws, L.off_status));
+  hipLaunchKernelGGL(k_running_sum<true>, dim3(stream_grid(L.n_tiles, 4)), dim3(kBlock), 0, S(stream), d_in,
+                     reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, (u32)L.n_tiles, ws_hdr(ws),
+                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

@@ -32,6 +32,7 @@ __device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[4][4], int lane) {
       const u32 ex = incl - c.w + run;
       run += wave_last(incl);
       c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+      __builtin_amdgcn_sched_barrier(0);  // one group at a time: interleaved scans cost ~40 VGPRs
     }
   return run;
 }
@@ -40,20 +41,13 @@ __device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[4][4], int lane) {
 // exchange wave totals, publish the tile total, look back, return the value to
 // add to every element of this wave.
 __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 seed, int lane,
-                                                 int wave, WsHeader* hdr, u64* status,
+                                                 int wave, WsHeader* hdr, const LbWords& lb,
                                                  u32* s_wave_tot, u32* s_prefix) {
   if (lane == 0) s_wave_tot[wave] = wave_tot;
   __syncthreads();
   if (wave == 0) {
     const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-    u32 excl = seed;
-    if (tile == 0) {
-      if (lane == 0) lb_publish(status, 0, kLbPfx, (u32)(seed + tile_tot));
-    } else {
-      if (lane == 0) lb_publish(status, tile, kLbAgg, tile_tot);
-      excl = (u32)lb_exclusive_prefix(status, tile, lane, &hdr->error);
-      if (lane == 0) lb_publish(status, tile, kLbPfx, (u32)(excl + tile_tot));
-    }
+    const u32 excl = seed + (u32)lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error);
     if (lane == 0) *s_prefix = excl;
   }
   __syncthreads();
@@ -66,7 +60,7 @@ template <int V, bool ZZ>
 __global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
     const u64* __restrict__ super_off, const u32* __restrict__ wt_rel, WsHeader* __restrict__ hdr,
-    u64* __restrict__ status, u64* __restrict__ consumed) {
+    LbWords lb, u64* __restrict__ consumed) {
   __shared__ WaveLds s_lds[kWaves];
   __shared__ u32 s_wave_tot[kWaves];
   __shared__ u32 s_prefix;
@@ -109,7 +103,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
     }
   }
   const u32 wave_tot = wave_running_sums(v, lane);
-  const u32 add = tile_value_prefix(wave_tot, tile, prev, lane, wave, hdr, status, s_wave_tot,
+  const u32 add = tile_value_prefix(wave_tot, tile, prev, lane, wave, hdr, lb, s_wave_tot,
                                     &s_prefix);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -242,51 +236,80 @@ __global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__
 // Plain inclusive running sum out[i] = seed + sum_{j<=i} f(in[j]), f = identity
 // or un-zigzag (zigzag_delta_decode).  8 B per value.
 template <bool ZZ>
-__global__ __launch_bounds__(kBlock, 3) void k_running_sum(const u32* __restrict__ in,
+__global__ __launch_bounds__(kBlock, 4) void k_running_sum(const u32* __restrict__ in,
                                                            u32* __restrict__ out, u32 count,
-                                                           u32 seed, WsHeader* __restrict__ hdr,
-                                                           u64* __restrict__ status) {
+                                                           u32 seed, u32 n_tiles,
+                                                           WsHeader* __restrict__ hdr, LbWords lb) {
   __shared__ u32 s_wave_tot[kWaves];
   __shared__ u32 s_prefix;
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
+  // persistent workgroups: tiles are drawn from the ticket until none is left
+  for (;;) {
   if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
   __syncthreads();
-  const u32 tile = s_tile;
+  const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
+  if (tile >= n_tiles) break;
   const u64 wave_first = ((u64)tile * kLbWt + (u64)wave * 4) * kWtInts;
   uint4 v[4][4];
+  const bool whole = wave_first + 4u * kWtInts <= count;  // wave-uniform: all 4096 values of this wave exist
+  if (whole) {
+    const uint4* src = reinterpret_cast<const uint4*>(in + wave_first);  // uniform base + lane offset
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u64 first = wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane);
-      uint4 r = make_uint4(0, 0, 0, 0);
-      if (first + 4 <= count) {
-        __builtin_memcpy(&r, in + first, 16);
+      for (int j = 0; j < 4; ++j) {
+        uint4 r = src[(u32)lane + (u32)(q * 256 + j * 64)];
         if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
-      } else if (first < count) {
-        r.x = in[first];
-        if (first + 1 < count) r.y = in[first + 1];
-        if (first + 2 < count) r.z = in[first + 2];
-        if (ZZ) {
-          r.x = zz_dec(r.x);
-          r.y = first + 1 < count ? zz_dec(r.y) : 0u;
-          r.z = first + 2 < count ? zz_dec(r.z) : 0u;
-        }
+        v[q][j] = r;
       }
-      v[q][j] = r;
-    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u64 first = wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane);
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (first + 4 <= count) {
+          __builtin_memcpy(&r, in + first, 16);
+          if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
+        } else if (first < count) {
+          r.x = in[first];
+          if (first + 1 < count) r.y = in[first + 1];
+          if (first + 2 < count) r.z = in[first + 2];
+          if (ZZ) {
+            r.x = zz_dec(r.x);
+            r.y = first + 1 < count ? zz_dec(r.y) : 0u;
+            r.z = first + 2 < count ? zz_dec(r.z) : 0u;
+          }
+        }
+        v[q][j] = r;
+      }
+  }
   const u32 wave_tot = wave_running_sums(v, lane);
-  const u32 add = tile_value_prefix(wave_tot, tile, seed, lane, wave, hdr, status, s_wave_tot,
+  const u32 add = tile_value_prefix(wave_tot, tile, seed, lane, wave, hdr, lb, s_wave_tot,
                                     &s_prefix);
+  if (whole) {
+    uint4* dst = reinterpret_cast<uint4*>(out + wave_first);
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint4 r = v[q][j];
-      r.x += add; r.y += add; r.z += add; r.w += add;
-      store_group(out, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count, r);
-    }
+      for (int j = 0; j < 4; ++j) {
+        uint4 r = v[q][j];
+        r.x += add; r.y += add; r.z += add; r.w += add;
+        dst[(u32)lane + (u32)(q * 256 + j * 64)] = r;
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4 r = v[q][j];
+        r.x += add; r.y += add; r.z += add; r.w += add;
+        store_group(out, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count, r);
+      }
+  }
+  }
 }
 
 }  // namespace svb
