@@ -1,87 +1,21 @@
-// Decoupled look-back: single-pass prefix sums across workgroups.
+// Decoupled look-back: single-pass prefix sums across workgroups, two levels.
 //
-// Each tile owns one 64-bit status word per channel:
-//     [63:62] 0 = nothing yet, 1 = AGGREGATE of this tile, 2 = inclusive PREFIX
+// Tiles draw their index from an atomic ticket, so every predecessor of a
+// running tile has itself started and will publish without waiting on anything
+// later: the chain cannot deadlock whatever the dispatch order.  A status word is
+//     [63:62] 0 = nothing yet, 1 = AGGREGATE, 2 = inclusive PREFIX
 //     [61:0]  the value
-// A word is written by ONE 8-byte agent-scope store and read by 8-byte
-// agent-scope loads, so flag and value travel together and no fence is needed
-// (the value is the whole payload).  Tiles draw their index from an atomic
-// ticket, so every predecessor of a running tile has itself started and will
-// publish without waiting on anything later: the chain cannot deadlock whatever
-// the dispatch order.  Every spin is bounded; on give-up the error word of the
+// written by ONE 8-byte agent-scope store and read by 8-byte agent-scope loads,
+// so flag and value travel together and no fence is needed (the value is the
+// whole payload).  Every spin is bounded; on give-up the error word of the
 // workspace header is set and the kernel still terminates.
-#pragma once
-#include "svb_device.h"
-
-namespace svb {
-
-constexpr u64 kLbAgg = 1ull << 62;
-constexpr u64 kLbPfx = 2ull << 62;
-constexpr u64 kLbVal = (1ull << 62) - 1;
-constexpr u32 kLbSpinLimit = 1u << 20;  // polls before giving up
-
-__device__ __forceinline__ void lb_publish(u64* status, u32 tile, u64 flag, u64 val) {
-  __hip_atomic_store(status + tile, flag | (val & kLbVal), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Sum of the aggregates of all tiles before `tile` (tile > 0), seeded by the
-// nearest published inclusive prefix.  Must be called by all 64 lanes of one
-// wavefront; returns the same value in every lane.
-template <int kLbWin = 4>  // status words polled per lane and round (window = 64 * kLbWin tiles)
-__device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, int lane,
-                                                   u32* err, u32* rounds_out = nullptr) {
-  u64 mine = 0;                          // this lane's share of the sum, reduced once at the end
-  long long base = (long long)tile - 1;  // nearest predecessor not yet summed
-  u32 spins = 0, rounds = 0;
-  while (true) {
-    ++rounds;
-    u64 s[kLbWin];
-#pragma unroll
-    for (int i = 0; i < kLbWin; ++i) {
-      const long long idx = base - lane - 64 * i;
-      s[i] = kLbPfx;  // before tile 0: an empty prefix ends the chain
-      if (idx >= 0)
-        s[i] = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    bool done = false, stall = false;
-#pragma unroll
-    for (int i = 0; i < kLbWin; ++i) {
-      if (!done && !stall) {
-        const u32 flag = (u32)(s[i] >> 62);
-        const u64 pfx = __ballot(flag == 2u);
-        const u64 inv = __ballot(flag == 0u);
-        const int first = pfx ? (int)__builtin_ctzll(pfx) : 64;       // nearest prefix lane
-        const u64 need = first >= 63 ? ~0ull : ((2ull << first) - 1);  // lanes 0..first
-        if (inv & need) {
-          stall = true;  // a word we need is not published yet
-        } else {
-          if (lane <= first) mine += s[i] & kLbVal;
-          if (first < 64) done = true;
-          else base -= 64;
-        }
-      }
-    }
-    if (done) break;
-    if (stall) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > kLbSpinLimit) {
-        if (lane == 0) atomicOr(err, 1u);
-        break;
-      }
-    }
-  }
-  const u64 prefix = wave_sum64(mine);
-  if (rounds_out) *rounds_out = rounds;
-  return prefix;
-}
-
-// ---- two-level look-back -----------------------------------------------------
+//
 // Polling is what a look-back costs: every agent-scope load of a status word
 // goes to memory, and a window of 256 words re-read by every waiting tile
-// slows the whole device down measurably, while the waiting itself is cheap
-// (so are not: atomic adds into shared words, which were tried for the group
-// aggregates and made every poll of those words several times slower).
+// (the classic one-level scheme, tried first) slows the whole device down
+// measurably, while the waiting itself is cheap.  Atomic adds into shared
+// words are not cheap either: tried for the group aggregates, they made every
+// poll of those words several times slower.
 // Here a tile polls ONE 8-byte word per lane and round:
 //   lanes  0..15  the words of the earlier tiles of its own GROUP of 16 tiles
 //                 (one 128-byte line),
@@ -92,6 +26,16 @@ __device__ __forceinline__ u64 lb_exclusive_prefix(const u64* status, u32 tile, 
 // A tile's exclusive prefix = tile words before it in its group + group
 // aggregates back to the nearest group prefix.  Only the lanes whose word was
 // not yet published poll again, about once a microsecond.
+#pragma once
+#include "svb_device.h"
+
+namespace svb {
+
+constexpr u64 kLbAgg = 1ull << 62;
+constexpr u64 kLbPfx = 2ull << 62;
+constexpr u64 kLbVal = (1ull << 62) - 1;
+constexpr u32 kLbSpinLimit = 1u << 20;  // polls before giving up
+
 struct LbWords {
   u64* tile;   // one word per tile: kLbAgg | value
   u64* group;  // one word per 16 tiles: kLbAgg | aggregate, later kLbPfx | inclusive prefix
@@ -107,7 +51,7 @@ __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, 
   u64 w = 0, mine = 0;
   long long gbase = (long long)k - 1;  // nearest group not yet summed
   bool tile_done = false, group_done = false;
-  u32 spins = 0, rounds = 0;
+  u32 spins = 0, rounds = 0, tile_round = 0, group_round = 0;  // the *_round values feed diagnostics only
   while (true) {
     ++rounds;
     if (tile_lane) {
@@ -123,6 +67,7 @@ __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, 
     if (!tile_done) {
       if (!__ballot(tile_lane && (u32)lane < r && flag == 0u)) {
         tile_done = true;
+        tile_round = rounds;
         const u64 v = (tile_lane && (u32)lane < r) ? (w & kLbVal) : 0ull;
         mine += v;
         if (leader) {  // the group is complete: let later groups count it
@@ -141,6 +86,7 @@ __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, 
         if (!tile_lane && lane <= first) mine += w & kLbVal;
         if (first < 64) {
           group_done = true;
+          group_round = rounds;
         } else {  // 48 aggregates and no prefix yet: go further back
           gbase -= kLbGroupLanes;
           if (!tile_lane) w = 0;
@@ -148,7 +94,9 @@ __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, 
       }
     }
     if (tile_done && group_done) break;
-    __builtin_amdgcn_s_sleep(40);
+    // every later tile waits for what a leader publishes: leaders poll eagerly
+    if (leader) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(40);
     if (++spins > kLbSpinLimit) {
       if (lane == 0) atomicOr(err, 1u);
       break;
@@ -157,7 +105,7 @@ __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, 
   const u64 prefix = wave_sum64(mine);
   if (leader && k && lane == 0)
     __hip_atomic_store(L.group + k, kLbPfx | (prefix + my_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (rounds_out) *rounds_out = rounds;
+  if (rounds_out) *rounds_out = rounds | (tile_round << 8) | (group_round << 16);
   return prefix;
 }
 

@@ -32,6 +32,15 @@ print(f"tiles {tiles}  kernel span {done.max():.1f} us")
 for name, v in (("load+classify", loaded - start), ("lookback", resolved - loaded), ("pass2", done - resolved), ("total", done - start)):
     print(f"{name:14s} mean {v.mean():7.2f}  p10 {np.percentile(v,10):7.2f}  p50 {np.percentile(v,50):7.2f}  p90 {np.percentile(v,90):7.2f}  max {v.max():7.2f} us")
 # how long after the predecessor resolved did this tile resolve, and after own publish?
+raw = st[:, 4].astype(np.int64)
+r_tile, r_group = (raw >> 8) & 0xFF, (raw >> 16) & 0xFF
+st[:, 4] = raw & 0xFF
+pos = np.arange(tiles) & 15
+lb = resolved - loaded
+print("position in group: look-back us / rounds until own group's tile words / until group words")
+for p_ in (0, 1, 4, 8, 12, 14, 15):
+    m = pos == p_
+    print(f"   r={p_:2d}  {lb[m].mean():6.2f} us   tile part {r_tile[m].mean():5.2f}   group part {r_group[m].mean():5.2f}   all {st[m, 4].mean():5.2f}")
 r = st[1:, 4]
 print("poll rounds: mean %.2f p50 %.0f p90 %.0f max %.0f; lookback us per round p50 %.2f" % (r.mean(), np.percentile(r,50), np.percentile(r,90), r.max(), np.percentile((resolved-loaded)[1:]/np.maximum(r,1),50)))
 print("resolve(i) - resolve(i-1): p50 %.3f p90 %.3f us" % (np.percentile(np.diff(resolved), 50), np.percentile(np.diff(resolved), 90)))
