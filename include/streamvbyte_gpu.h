@@ -53,7 +53,7 @@ int svbgpu_device_ok(void);
  *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
  *                               streaming passes; 1: single pass with look-back
  *   "debug_ablate" = bits       timing-only diagnostics, results become wrong
- * Results never depend on a knob, only speed. */
+ * Apart from "debug_ablate", results never depend on a knob, only speed. */
 int svbgpu_set_option(const char *name, int value);
 
 /* Device scratch any single-stream call below needs for `count` values.

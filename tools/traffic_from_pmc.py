@@ -28,4 +28,6 @@ for k in sorted(set(f) | set(w)):
     fk, wk = f.get(k, 0.0), w.get(k, 0.0)
     out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes": int((2 * fk + wk) * 1024)}
 json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, n = 2^28 (2^26 for the 0124 zigzag kernels), "
-                   "tools/microbench.py inputs", "kernels": out}, sys.stdout, indent=1)
+                   "tools/microbench.py inputs; a kernel launched on several workloads is reported for the "
+                   "largest one (the delta decoders: deltas of full-width values, ~3.75 data bytes per value)",
+           "kernels": out}, sys.stdout, indent=1)
