@@ -47,7 +47,7 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
   __syncthreads();
   if (wave == 0) {
     const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-    const u32 excl = seed + (u32)lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error);
+    const u32 excl = seed + (u32)lb2_exclusive_prefix<1>(lb, tile, tile_tot, lane, &hdr->error);
     if (lane == 0) *s_prefix = excl;
   }
   __syncthreads();

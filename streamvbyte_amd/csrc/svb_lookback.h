@@ -40,56 +40,73 @@ struct LbWords {
   u64* tile;   // one word per tile: kLbAgg | value
   u64* group;  // one word per 16 tiles: kLbAgg | aggregate, later kLbPfx | inclusive prefix
 };
-constexpr int kLbGroupLanes = 48;
-
+// kT = tile words polled per lane: the window of tiles read one by one covers
+// the tile's own group and the 4 kT - 1 groups before it.
+template <int kT = 2>
 __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, u64 my_agg, int lane,
                                                     u32* err, u32* rounds_out = nullptr) {
-  const u32 k = tile >> 4, r = tile & 15u;
+  constexpr u32 kDirect = 4 * kT - 1;
+  const u32 k = tile >> 4;
+  const u32 g0 = k > kDirect ? k - kDirect : 0u;  // first group of the tile window
+  const int t0 = 16 * (int)g0;  // tile and group indices fit 32 bits (at most 2^20 tiles)
   if (lane == 0) __hip_atomic_store(L.tile + tile, kLbAgg | my_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool tile_lane = lane < 16;
-  const bool leader = r == 15u;
-  u64 w = 0, mine = 0;
-  long long gbase = (long long)k - 1;  // nearest group not yet summed
-  bool tile_done = false, group_done = false;
+  const bool leader = (tile & 15u) == 15u;
+  u64 tw[kT], gw = 0, mine = 0;
+#pragma unroll
+  for (int i = 0; i < kT; ++i) tw[i] = 0;
+  int gbase = (int)g0 - 1;  // nearest group not yet summed
+  bool tile_done = false, group_done = false, agg_out = false;
   u32 spins = 0, rounds = 0, tile_round = 0, group_round = 0;  // the *_round values feed diagnostics only
   while (true) {
     ++rounds;
-    if (tile_lane) {
-      if (!tile_done && (u32)lane < r && (w >> 62) == 0)
-        w = __hip_atomic_load(L.tile + (tile - r) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (!group_done) {
-      const long long idx = gbase - (lane - 16);
-      if (idx < 0) w = kLbPfx;  // before group 0: an empty prefix ends the chain
-      else if ((w >> 62) == 0)
-        w = __hip_atomic_load(L.group + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const u32 flag = (u32)(w >> 62);
     if (!tile_done) {
-      if (!__ballot(tile_lane && (u32)lane < r && flag == 0u)) {
-        tile_done = true;
-        tile_round = rounds;
-        const u64 v = (tile_lane && (u32)lane < r) ? (w & kLbVal) : 0ull;
-        mine += v;
-        if (leader) {  // the group is complete: let later groups count it
-          const u64 gagg = wave_sum64(v) + my_agg;
-          if (lane == 0)
-            __hip_atomic_store(L.group + k, (k ? kLbAgg : kLbPfx) | gagg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+#pragma unroll
+      for (int i = 0; i < kT; ++i) {
+        const int idx = (int)tile - 1 - lane - 64 * i;
+        if (idx >= t0 && (tw[i] >> 62) == 0)
+          tw[i] = __hip_atomic_load(L.tile + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (!group_done) {
-      const u64 pfx = __ballot(!tile_lane && flag == 2u);
-      const u64 inv = __ballot(!tile_lane && flag == 0u);
-      const int first = pfx ? (int)__builtin_ctzll(pfx) : 64;  // nearest group prefix
-      const u64 need = (first >= 63 ? ~0ull : ((2ull << first) - 1)) & ~0xFFFFull;  // lanes 16..first
+      const int idx = gbase - lane;
+      if (idx < 0) gw = kLbPfx;  // before group 0: an empty prefix ends the chain
+      else if ((gw >> 62) == 0)
+        gw = __hip_atomic_load(L.group + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (leader && !agg_out && !__ballot(lane < 15 && (tw[0] >> 62) == 0)) {
+      // the group is complete: let later groups count it
+      agg_out = true;
+      const u64 gagg = wave_sum64(lane < 15 ? (tw[0] & kLbVal) : 0ull) + my_agg;
+      if (lane == 0)
+        __hip_atomic_store(L.group + k, (k ? kLbAgg : kLbPfx) | gagg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!tile_done) {
+      bool missing = false;
+#pragma unroll
+      for (int i = 0; i < kT; ++i)
+        missing |= ((int)tile - 1 - lane - 64 * i >= t0) && (tw[i] >> 62) == 0;
+      if (!__ballot(missing)) {
+        tile_done = true;
+        tile_round = rounds;
+#pragma unroll
+        for (int i = 0; i < kT; ++i)
+          if ((int)tile - 1 - lane - 64 * i >= t0) mine += tw[i] & kLbVal;
+      }
+    }
+    if (!group_done) {
+      const u32 flag = (u32)(gw >> 62);
+      const u64 pfx = __ballot(flag == 2u);
+      const u64 inv = __ballot(flag == 0u);
+      const int first = pfx ? (int)__builtin_ctzll(pfx) : 64;       // nearest group prefix
+      const u64 need = first >= 63 ? ~0ull : ((2ull << first) - 1);  // lanes 0..first
       if (!(inv & need)) {
-        if (!tile_lane && lane <= first) mine += w & kLbVal;
+        if (lane <= first) mine += gw & kLbVal;
         if (first < 64) {
           group_done = true;
           group_round = rounds;
-        } else {  // 48 aggregates and no prefix yet: go further back
-          gbase -= kLbGroupLanes;
-          if (!tile_lane) w = 0;
+        } else {  // 64 aggregates and no prefix yet: go further back
+          gbase -= 64;
+          gw = 0;
         }
       }
     }
