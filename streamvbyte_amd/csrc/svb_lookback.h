@@ -16,16 +16,17 @@
 // measurably, while the waiting itself is cheap.  Atomic adds into shared
 // words are not cheap either: tried for the group aggregates, they made every
 // poll of those words several times slower.
-// Here a tile polls ONE 8-byte word per lane and round:
-//   lanes  0..15  the words of the earlier tiles of its own GROUP of 16 tiles
-//                 (one 128-byte line),
-//   lanes 16..63  the words of the 48 groups before its own.
+// Here a tile polls at most kT + 1 eight-byte words per lane and round:
+//   kT tile words: the earlier tiles of its own GROUP of 16 tiles and all tiles
+//                  of the 4 kT - 1 groups before it (a window of < 64 kT tiles),
+//   1 group word:  the 64 groups before that window.
 // The last tile of a group (its leader) publishes the group's aggregate as soon
 // as the 15 other tile words are in, and the group's inclusive prefix once its
-// own look-back over the group words has ended; nobody else writes group words.
-// A tile's exclusive prefix = tile words before it in its group + group
-// aggregates back to the nearest group prefix.  Only the lanes whose word was
-// not yet published poll again, about once a microsecond.
+// own look-back has ended; nobody else writes group words.  Group words are read
+// only for groups at least 4 kT groups back, whose leaders have long published.
+// A tile's exclusive prefix = tile words of its window + group aggregates back
+// to the nearest group prefix.  Only the lanes whose word was not yet published
+// poll again, about once a microsecond.
 #pragma once
 #include "svb_device.h"
 
