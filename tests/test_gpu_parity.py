@@ -212,3 +212,70 @@ def test_batched_streams(torch_mod, codec, oracle):
         used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
         assert np.array_equal(used.cpu().numpy(), h_sizes)
         assert np.array_equal(to_np(back, np.uint32), values)
+
+
+def _expected_stream(oracle, variant, flags, v_u32, prev):
+    """What the reference's functions chained on the CPU give for this flag set:
+    [zigzag_delta_encode | zigzag_encode | delta] then encode / encode_0124."""
+    from streamvbyte_amd import DELTA, ZIGZAG
+    if flags & ZIGZAG:
+        signed = v_u32.view(np.int32)
+        sprev = prev - (1 << 32) if prev >= (1 << 31) else prev
+        pre = oracle.zigzag_delta_encode(signed, sprev) if flags & DELTA else oracle.zigzag_encode(signed)
+        return oracle.encode(variant, pre)
+    return oracle.encode(variant, v_u32, bool(flags & DELTA), prev)
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+@pytest.mark.parametrize("flagbits", [0, 1, 2, 3])
+def test_every_variant_and_flag_combination(torch_mod, codec, oracle, variant, flagbits):
+    """All 8 combinations of {1234, 0124} x {plain, delta, zigzag, zigzag+delta}: the fused
+    kernels equal the reference's functions applied one after the other."""
+    from streamvbyte_amd import DELTA, ZIGZAG
+    flags = (DELTA if flagbits & 1 else 0) | (ZIGZAG if flagbits & 2 else 0)
+    for i, n in enumerate([1, 4, 5, 255, 1024, 1025, 4097, 16384, 16385, 70001, 300007]):
+        v = gen(["sparse", "width_mix", "postings"][i % 3], n, 7000 + 16 * flagbits + i)
+        prev = [0, 0xFFFFFFF0, 12345][i % 3] if flags & DELTA else 0
+        expect = _expected_stream(oracle, variant, flags, v, prev)
+        out, size = codec.encode(to_dev(torch_mod, v), variant=variant, flags=flags, prev=prev)
+        codec.check()
+        assert int(size.item()) == expect.size, (n,)
+        assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n,)
+        assert int(codec.compressedbytes(to_dev(torch_mod, v), variant=variant, flags=flags, prev=prev).item()) == expect.size
+        dec, used = codec.decode(dev_stream(torch_mod, expect), n, variant=variant, flags=flags, prev=prev)
+        codec.check()
+        assert int(used.item()) == expect.size
+        assert np.array_equal(to_np(dec, np.uint32), v), (n,)
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+@pytest.mark.parametrize("flagbits", [1, 2, 3])
+def test_batched_flag_combinations(torch_mod, codec, oracle, variant, flagbits):
+    from streamvbyte_amd import DELTA, ZIGZAG, streamvbyte_max_compressedbytes
+    torch = torch_mod
+    flags = (DELTA if flagbits & 1 else 0) | (ZIGZAG if flagbits & 2 else 0)
+    rng = np.random.default_rng(500 + flagbits)
+    ns = 400
+    counts = np.floor(np.exp(rng.uniform(0, np.log(3000), size=ns))).astype(np.uint32)
+    counts[:6] = [0, 1, 255, 256, 257, 2049]
+    prevs = rng.integers(0, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)
+    voff = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    cap = np.array([streamvbyte_max_compressedbytes(int(c)) for c in counts], dtype=np.uint64)
+    boff = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+    values = np.concatenate([GENERATORS["sparse" if k % 2 else "width_mix"](rng, int(c)) for k, c in enumerate(counts)])
+    d_values = to_dev(torch, values)
+    d_voff = torch.from_numpy(voff[:-1].astype(np.int64)).cuda()
+    d_boff = torch.from_numpy(boff[:-1].astype(np.int64)).cuda()
+    d_counts, d_prevs = to_dev(torch, counts), to_dev(torch, prevs)
+    buf = torch.zeros(int(boff[-1]) + 16, dtype=torch.uint8, device="cuda:0")
+    sizes = codec.encode_batch(d_values, d_voff, buf, d_boff, d_counts, d_prevs, variant=variant, flags=flags)
+    h_sizes, h_buf = sizes.cpu().numpy(), buf.cpu().numpy()
+    for s in range(ns):
+        v = values[int(voff[s]): int(voff[s + 1])]
+        expect = _expected_stream(oracle, variant, flags, v, int(prevs[s]) if flags & DELTA else 0)
+        assert h_sizes[s] == expect.size, (s, counts[s])
+        assert np.array_equal(h_buf[int(boff[s]): int(boff[s]) + expect.size], expect), (s, counts[s])
+    back = torch.zeros_like(d_values)
+    used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+    assert np.array_equal(used.cpu().numpy(), h_sizes)
+    assert np.array_equal(to_np(back, np.uint32), values)
