@@ -33,6 +33,10 @@ extern "C" {
 #define SVBGPU_ZIGZAG 2u /* encode: values are int32, zigzag-mapped before coding;
                             decode: un-zigzag after decoding (fuses zigzag_encode/
                             zigzag_decode into the codec pass)                      */
+/* Both variants take every combination of the flags.  DELTA | ZIGZAG codes
+ * zigzag(in[i] - in[i-1]), i.e. zigzag_delta_encode (reference
+ * src/streamvbyte_zigzag.c:13-18) followed by the encoder, in one pass; the
+ * reference itself offers delta only for 1234 (include/streamvbytedelta.h). */
 
 #define SVBGPU_OK 0
 #define SVBGPU_EINVAL (-1)     /* bad argument                                   */
