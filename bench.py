@@ -150,8 +150,22 @@ def cpu_baseline(values_host, threads_all):
 
     t_dec_all = best_of(lambda: run_all(lambda i: dec(comps[i], outs[i], per)), 3)
     t_enc_all = best_of(lambda: run_all(lambda i: enc(parts[i], comps[i])), 3)
+    # the reference's own benchmark shape (tests/perf.c:52-53 there): 500 000 values
+    # v = r31 >> (s & 31), cache-resident, best of 100 trials
+    rng = np.random.default_rng(1)
+    c1 = (rng.integers(0, 1 << 31, size=500000, dtype=np.uint64) >> (rng.integers(0, 1 << 31, size=500000, dtype=np.uint64) & 31)).astype(np.uint32)
+    c1_comp = np.zeros(max_compressedbytes(c1.size), dtype=np.uint8)
+    c1_size = enc(c1, c1_comp)
+    c1_back = np.empty(c1.size, dtype=np.uint32)
+    t_c1_dec = best_of(lambda: dec(c1_comp, c1_back, c1.size), 100)
+    t_c1_enc = best_of(lambda: enc(c1, c1_comp), 100)
+    assert np.array_equal(c1_back, c1)
     gb = 4.0 * n / 1e9
     return {
+        "perf_c_500k": {"decode_GBps": round(4.0 * c1.size / 1e9 / t_c1_dec, 3),
+                        "encode_GBps": round(4.0 * c1.size / 1e9 / t_c1_enc, 3),
+                        "stream_bytes": int(c1_size), "cores": 1,
+                        "note": "500 000 values r31 >> (s & 31), cache-resident, best of 100"},
         "value": round(gb / t_dec, 3), "unit": "GB/s (uint32 out, decode)", "cores": 1, "kind": cpu.kind,
         "sample": f"first 2^{int(np.log2(n))} values of the workload, best of {reps}, DRAM-resident "
                   f"({size} B stream)",
@@ -319,6 +333,26 @@ def main():
                                    "decode_roofline_frac": round((4.25 + d3) * n3 / ms_d / 1e6 / HBM_PEAK_GBS, 4),
                                    "encode_roofline_frac": round((4.25 + d3) * n3 / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
         del post, s3
+        # C3 mixed: 1-3 byte gaps, running sum wraps modulo 2^32, prev != 0
+        n3b = min(n, 1 << 26)
+        r31 = torch.randint(0, 1 << 31, (n3b,), generator=g, device=device, dtype=torch.int64)
+        sh = torch.randint(0, 32, (n3b,), generator=g, device=device, dtype=torch.int64)
+        gaps = (r31 >> sh) >> 8
+        post = (torch.cumsum(gaps, 0) + 0xDEADBEEF) & 0xFFFFFFFF
+        post = torch.where(post >= (1 << 31), post - (1 << 32), post).to(torch.int32)
+        del r31, sh, gaps
+        s3, z3 = codec.encode(post, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF)
+        d3b = (int(z3.item()) - (n3b + 3) // 4) / n3b
+        o3 = out[:n3b]
+        ms_e, _ = event_ms(torch, lambda: codec.encode(post, out=enc_out, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF), it)
+        ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
+        codec.check()
+        extra["delta_mixed_gaps"] = {"n": n3b, "data_bytes_per_value": round(d3b, 4), "prev": "0xDEADBEEF",
+                                     "parity": bool(torch.equal(o3, post)),
+                                     "decode_GBps": round(4.0 * n3b / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n3b / ms_e / 1e6, 1),
+                                     "decode_roofline_frac": round((4.25 + d3b) * n3b / ms_d / 1e6 / HBM_PEAK_GBS, 4),
+                                     "encode_roofline_frac": round((4.25 + d3b) * n3b / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
+        del post, s3
         # C4 gradients: int32 ~ round(N(0,0.8)) with 0.1% outliers, zigzag fused into the 0124 codec
         n4 = min(n, 1 << 26)
         gr = torch.round(torch.randn(n4, generator=g, device=device) * 0.8).to(torch.int32)
@@ -387,6 +421,13 @@ def main():
                           "encode_GBps": round(4.0 * tot_all * kb / tb_e / 1e9, 1),
                           "decode_roofline_frac": round((4.25 + dB) * tot_all * kb / tb_d / 1e9 / HBM_PEAK_GBS / world, 4),
                           "encode_roofline_frac": round((4.25 + dB) * tot_all * kb / tb_e / 1e9 / HBM_PEAK_GBS / world, 4)}
+        # the same lists coded without delta (mixed widths)
+        tb_e2 = time_steps(torch, lambda: codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=0, sizes=sizes), kb, 1, dist)
+        tb_d2 = time_steps(torch, lambda: codec.decode_batch(bbuf, boff[:-1], back, voff[:-1], counts, None, flags=0), kb, 1, dist)
+        dB2 = float((sizes.sum().item() - ((counts.to(torch.int64) + 3) // 4).sum().item()) / tot)
+        res["batched"]["plain"] = {"data_bytes_per_value": round(dB2, 4), "parity": bool(torch.equal(back, vals)),
+                                   "decode_GBps": round(4.0 * tot_all * kb / tb_d2 / 1e9, 1),
+                                   "encode_GBps": round(4.0 * tot_all * kb / tb_e2 / 1e9, 1)}
         del vals, back, bbuf
 
         if rank == 0 and world == 1:
