@@ -135,6 +135,57 @@ def _check(rc, what):
         raise SvbError(f"{what}: {load().svbgpu_strerror(rc).decode()} ({rc})")
 
 
+# ---- frames (include/streamvbyte_frame.h), host memory -------------------------
+FRAME_ERRORS = {-11: "buffer ends inside a frame", -12: "bad frame header", -13: "output buffer too small",
+                -14: "a payload fails streamvbyte_validate_stream"}
+
+
+def _check_frame(rc, what):
+    if rc in FRAME_ERRORS:
+        raise SvbError(f"{what}: {FRAME_ERRORS[rc]} ({rc})")
+    _check(rc, what)
+
+
+def frame_peek(frames, offset=0):
+    """Header of the frame at `offset` of a uint8 array -> FrameInfo."""
+    from ._lib import FrameInfo
+    f = _np(frames, np.uint8)
+    info = FrameInfo()
+    _check_frame(load().svbframe_peek(f.ctypes.data + offset, f.size - offset, C.addressof(info)), "svbframe_peek")
+    return info
+
+
+def frame_scan(frames):
+    """(number of frames, number of values) of consecutive frames."""
+    f = _np(frames, np.uint8)
+    nf, nv = C.c_size_t(0), C.c_size_t(0)
+    _check_frame(load().svbframe_scan(_ptr(f), f.size, C.addressof(nf), C.addressof(nv)), "svbframe_scan")
+    return nf.value, nv.value
+
+
+def frame_encode_many(values, frame_values, variant=V1234, flags=0):
+    """values -> consecutive frames of at most frame_values values (uint8 array)."""
+    lib = load()
+    v = _np(values, np.uint32)
+    cap = lib.svbframe_max_bytes_many(v.size, frame_values)
+    out = np.empty(cap, dtype=np.uint8)
+    written = C.c_size_t(0)
+    _check_frame(lib.svbframe_encode_many(_ptr(v), v.size, frame_values, variant, flags, _ptr(out), cap,
+                                          C.addressof(written)), "svbframe_encode_many")
+    return out[:written.value].copy()
+
+
+def frame_decode_many(frames):
+    """consecutive frames -> uint32 array of all their values."""
+    lib = load()
+    f = _np(frames, np.uint8)
+    n = C.c_size_t(0)
+    _check_frame(lib.svbframe_decode_many(_ptr(f), f.size, None, 0, C.addressof(n)), "svbframe_decode_many")
+    out = np.empty(n.value, dtype=np.uint32)
+    _check_frame(lib.svbframe_decode_many(_ptr(f), f.size, _ptr(out), out.size, C.addressof(n)), "svbframe_decode_many")
+    return out
+
+
 class DeviceCodec:
     """Device-pointer API on torch tensors (include/streamvbyte_gpu.h).
 

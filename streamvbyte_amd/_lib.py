@@ -45,9 +45,48 @@ SIGNATURES = {
     "svbgpu_zigzag_delta_decode": (C.c_int, [vp, vp, C.c_size_t, C.c_int32, vp, C.c_size_t, vp]),
     "svbgpu_encode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbgpu_decode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    # include/streamvbyte_frame.h
+    "svbframe_max_bytes": (C.c_size_t, [C.c_uint32]),
+    "svbframe_max_bytes_many": (C.c_size_t, [C.c_size_t, C.c_uint32]),
+    "svbframe_peek": (C.c_int, [vp, C.c_size_t, vp]),
+    "svbframe_scan": (C.c_int, [vp, C.c_size_t, vp, vp]),
+    "svbframe_encode_many": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.c_int, C.c_uint, vp, C.c_size_t, vp]),
+    "svbframe_decode_many": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp]),
+    "svbframe_alloc_pinned": (vp, [C.c_size_t]),
+    "svbframe_free_pinned": (None, [vp]),
 }
 
+
+class FrameInfo(C.Structure):
+    """svbframe_info of include/streamvbyte_frame.h"""
+    _fields_ = [("count", C.c_uint32), ("prev", C.c_uint32), ("variant", C.c_uint8), ("flags", C.c_uint8),
+                ("stream_bytes", C.c_uint64), ("frame_bytes", C.c_uint64)]
+
 _lib = None
+
+
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.7.  Two HIP runtimes in one
+    process leave the one initialised second without a device, so where torch
+    is installed but not imported yet its copy is loaded first; ours then
+    resolves to it by soname, exactly as it does when torch was imported
+    first.  Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -58,6 +97,7 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m streamvbyte_amd.build` "
                 "(hipcc, gfx950). streamvbyte_amd has no CPU implementation to fall back to.")
+        _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -5,6 +5,7 @@
 // codec in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -720,3 +721,5 @@ void zigzag_delta_decode(const uint32_t* in, int32_t* out, size_t N, int32_t pre
 }
 
 }  // extern "C"
+
+#include "svb_frame.h"
