@@ -12,7 +12,8 @@
 namespace {
 
 constexpr uint32_t kFrameMagic = 0x46425653u;  // "SVBF"
-constexpr int kFrameSlots = 3;
+constexpr int kFrameSlots = 4;
+constexpr size_t kFrameLag = 3;  // < kFrameSlots + 1: a slot's stage 2 is queued before its next stage 1
 
 struct FrameHdr {
   uint32_t magic;
@@ -50,7 +51,9 @@ struct HostPin {
 // later would free memory that queued work still uses).
 struct FrameSlots {
   Ctx* c[kFrameSlots] = {};
-  hipEvent_t ev[kFrameSlots] = {};
+  hipEvent_t ev[kFrameSlots] = {};    // result word of the slot's frame is back
+  hipEvent_t up[kFrameSlots] = {};    // the slot's host-to-device copy has ended
+  hipEvent_t down[kFrameSlots] = {};  // the slot's device-to-host copy has ended
   int n = 0;
   int init(size_t a_bytes, size_t b_bytes, uint32_t max_count) {
     for (n = 0; n < kFrameSlots; ++n) {
@@ -62,11 +65,31 @@ struct FrameSlots {
         ctx_release(c[n]);
         return SVBGPU_EHIP;
       }
-      if (hipEventCreateWithFlags(&ev[n], hipEventDisableTiming) != hipSuccess) {
+      if (hipEventCreateWithFlags(&ev[n], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&up[n], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&down[n], hipEventDisableTiming) != hipSuccess) {
         ctx_release(c[n]);
         return SVBGPU_EHIP;
       }
     }
+    return SVBGPU_OK;
+  }
+  // Copies of one direction run one after the other in frame order (each waits
+  // for the previous frame's), so that a frame's upload ends early and its
+  // kernels and download overlap the next frames' uploads; left alone, the
+  // slots' copies share the link, end together and the two directions take turns.
+  int copy_up(size_t i, void* dst, const void* src, size_t bytes) {
+    const int s = (int)(i % kFrameSlots), p = (int)((i + kFrameSlots - 1) % kFrameSlots);
+    if (i) HIP_TRY(hipStreamWaitEvent(c[s]->stream, up[p], 0));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c[s]->stream));
+    HIP_TRY(hipEventRecord(up[s], c[s]->stream));
+    return SVBGPU_OK;
+  }
+  int copy_down(size_t i, void* dst, const void* src, size_t bytes) {
+    const int s = (int)(i % kFrameSlots), p = (int)((i + kFrameSlots - 1) % kFrameSlots);
+    if (i) HIP_TRY(hipStreamWaitEvent(c[s]->stream, down[p], 0));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c[s]->stream));
+    HIP_TRY(hipEventRecord(down[s], c[s]->stream));
     return SVBGPU_OK;
   }
   int drain() {
@@ -79,6 +102,8 @@ struct FrameSlots {
     for (int i = 0; i < n; ++i) {
       (void)hipStreamSynchronize(c[i]->stream);
       (void)hipEventDestroy(ev[i]);
+      (void)hipEventDestroy(up[i]);
+      (void)hipEventDestroy(down[i]);
       ctx_release(c[i]);
     }
   }
@@ -175,8 +200,9 @@ int svbframe_encode_many(const uint32_t* in, size_t n, uint32_t frame_values, in
     const uint32_t cnt = count_of(i);
     const uint32_t* src = in + i * frame_values;
     const uint32_t prev = (flags & SVBGPU_DELTA) && i ? src[-1] : 0u;
-    HIP_TRY(hipMemcpyAsync(c->a, src, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
-    int r = svbgpu_encode(variant, flags, static_cast<const uint32_t*>(c->a), cnt, static_cast<uint8_t*>(c->b),
+    int r = S.copy_up(i, c->a, src, (size_t)cnt * 4);
+    if (r) return r;
+    r = svbgpu_encode(variant, flags, static_cast<const uint32_t*>(c->a), cnt, static_cast<uint8_t*>(c->b),
                           prev, c->ws, c->ws_cap, c->d_res, c->stream);
     if (r) return r;
     HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, 8, hipMemcpyDeviceToHost, c->stream));
@@ -199,17 +225,18 @@ int svbframe_encode_many(const uint32_t* in, size_t n, uint32_t frame_values, in
     h.prev = (flags & SVBGPU_DELTA) && i ? in[i * frame_values - 1] : 0u;
     h.stream_bytes = sz;
     std::memcpy(out + off, &h, sizeof(h));
-    HIP_TRY(hipMemcpyAsync(out + off + SVBFRAME_HEADER_BYTES, c->b, sz, hipMemcpyDeviceToHost, c->stream));
+    const int r = S.copy_down(i, out + off + SVBFRAME_HEADER_BYTES, c->b, sz);
+    if (r) return r;
     const uint64_t padded = round16(sz);
     std::memset(out + off + SVBFRAME_HEADER_BYTES + sz, 0, padded - sz);
     off += SVBFRAME_HEADER_BYTES + padded;
     return SVBGPU_OK;
   };
-  for (size_t i = 0; i < nframes && !rc; ++i) {
-    rc = stage1(i);
-    if (!rc && i >= 1) rc = stage2(i - 1);
+  // the host stays kFrameLag frames ahead of the results it waits for
+  for (size_t i = 0; i < nframes + kFrameLag && !rc; ++i) {
+    if (i < nframes) rc = stage1(i);
+    if (!rc && i >= kFrameLag) rc = stage2(i - kFrameLag);
   }
-  if (!rc) rc = stage2(nframes - 1);
   const int rd = S.drain();
   if (!rc) rc = rd;
   for (int s = 0; s < S.n && !rc; ++s) rc = svbgpu_check_status(S.c[s]->ws, S.c[s]->stream);
@@ -252,9 +279,9 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
   auto stage1 = [&](size_t i) -> int {
     Ctx* c = S.c[i % kFrameSlots];
     const Ref& f = fr[i];
-    HIP_TRY(hipMemcpyAsync(c->a, frames + f.off + SVBFRAME_HEADER_BYTES, f.inf.stream_bytes,
-                           hipMemcpyHostToDevice, c->stream));
-    int r = svbgpu_validate(f.inf.variant, static_cast<const uint8_t*>(c->a), f.inf.stream_bytes, f.inf.count,
+    int r = S.copy_up(i, c->a, frames + f.off + SVBFRAME_HEADER_BYTES, f.inf.stream_bytes);
+    if (r) return r;
+    r = svbgpu_validate(f.inf.variant, static_cast<const uint8_t*>(c->a), f.inf.stream_bytes, f.inf.count,
                             reinterpret_cast<uint32_t*>(c->d_res + 1), c->ws, c->ws_cap, c->stream);
     if (r) return r;
     HIP_TRY(hipMemcpyAsync(c->h_res + 1, c->d_res + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -271,14 +298,12 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
                           static_cast<uint32_t*>(c->b), f.inf.count, f.inf.prev, c->ws, c->ws_cap, nullptr,
                           c->stream);
     if (r) return r;
-    HIP_TRY(hipMemcpyAsync(out + f.voff, c->b, (size_t)f.inf.count * 4, hipMemcpyDeviceToHost, c->stream));
-    return SVBGPU_OK;
+    return S.copy_down(i, out + f.voff, c->b, (size_t)f.inf.count * 4);
   };
-  for (size_t i = 0; i < fr.size() && !rc; ++i) {
-    rc = stage1(i);
-    if (!rc && i >= 1) rc = stage2(i - 1);
+  for (size_t i = 0; i < fr.size() + kFrameLag && !rc; ++i) {
+    if (i < fr.size()) rc = stage1(i);
+    if (!rc && i >= kFrameLag) rc = stage2(i - kFrameLag);
   }
-  if (!rc) rc = stage2(fr.size() - 1);
   const int rd = S.drain();
   if (!rc) rc = rd;
   for (int s = 0; s < S.n && !rc; ++s) rc = svbgpu_check_status(S.c[s]->ws, S.c[s]->stream);
