@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include "streamvbyte.h"
+#include "streamvbyte_frame.h"
+#include "streamvbyte_gpu.h"
 #include "streamvbyte_zigzag.h"
 #include "streamvbytedelta.h"
 
@@ -34,6 +36,17 @@ int main(void) {
   uint32_t *tmp = malloc(n * 4);
   zigzag_delta_decode(back, (int32_t *)tmp, n, -3);
   if (memcmp(in, tmp, n * 4)) return 9;
+  /* frames: pageable host buffers, three frames, delta coded */
+  size_t cap = svbframe_max_bytes_many(n, 40000), written = 0, nvalues = 0;
+  uint8_t *frames = malloc(cap);
+  if (svbframe_encode_many(in, n, 40000, SVBGPU_1234, SVBGPU_DELTA, frames, cap, &written) != SVBFRAME_OK) return 10;
+  svbframe_info info;
+  if (svbframe_peek(frames, written, &info) != SVBFRAME_OK || info.count != 40000 || info.flags != SVBGPU_DELTA) return 11;
+  if (svbframe_decode_many(frames, written, NULL, 0, &nvalues) != SVBFRAME_OK || nvalues != n) return 12;
+  memset(tmp, 0, n * 4);
+  if (svbframe_decode_many(frames, written, tmp, n, &nvalues) != SVBFRAME_OK || memcmp(in, tmp, n * 4)) return 13;
+  frames[3] ^= 0x40; /* magic */
+  if (svbframe_decode_many(frames, written, tmp, n, &nvalues) != SVBFRAME_EBADFRAME) return 14;
   printf("drop-in round trips ok (%zu bytes)\n", a);
   return 0;
 }
