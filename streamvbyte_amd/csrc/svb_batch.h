@@ -75,14 +75,6 @@ __device__ __forceinline__ u32 row_scan_incl(u32 x) {
 // value of lane 15 of the caller's row
 __device__ __forceinline__ u32 row_last(u32 x, int lane) { return __shfl(x, (lane & 48) | 15, 64); }
 
-// bytes [o, o+4) of the 16-byte little-endian value d (o = 0..12), zero beyond
-__device__ __forceinline__ u32 bytes_at(const uint4& d, u32 o) {
-  const u32 i = o >> 2;
-  const u32 lo = i == 0 ? d.x : (i == 1 ? d.y : (i == 2 ? d.z : d.w));
-  const u32 hi = i == 0 ? d.y : (i == 1 ? d.z : (i == 2 ? d.w : 0u));
-  return __builtin_amdgcn_alignbyte(hi, lo, o);
-}
-
 template <int V, bool DELTA, bool ZZ>
 __global__ __launch_bounds__(kBlock) void k_decode_batch_rows(
     const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
@@ -110,24 +102,13 @@ __global__ __launch_bounds__(kBlock) void k_decode_batch_rows(
       u32 key = have ? in[g] : 0u;
       const u32 nv = have ? min(4u, count - 4u * g) : 0u;
       key &= nv >= 4u ? 0xFFu : ((1u << (2u * nv)) - 1u);
-      u32 l[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) l[k] = (u32)k < nv ? len_of<V>((key >> (2 * k)) & 3u) : 0u;
-      const u32 L = l[0] + l[1] + l[2] + l[3];
+      const u32 L = group_len<V>(key, nv);
       const u32 incl = row_scan_incl(L);
       const u32 off = doff + incl - L;
       doff += row_last(incl, lane);
       uint4 d = make_uint4(0, 0, 0, 0);
       if (have) d = ld_u128(data + off);
-      uint4 c;
-      c.x = bytes_at(d, 0) & (l[0] ? mask_of<V>(key & 3u) : 0u);
-      c.y = bytes_at(d, l[0]) & (l[1] ? mask_of<V>((key >> 2) & 3u) : 0u);
-      c.z = bytes_at(d, l[0] + l[1]) & (l[2] ? mask_of<V>((key >> 4) & 3u) : 0u);
-      c.w = bytes_at(d, l[0] + l[1] + l[2]) & (l[3] ? mask_of<V>((key >> 6) & 3u) : 0u);
-      if (ZZ) {
-        c = make_uint4(zz_dec(c.x), zz_dec(c.y), zz_dec(c.z), zz_dec(c.w));
-        if (nv < 4u) { c.w = 0; if (nv < 3u) c.z = 0; if (nv < 2u) c.y = 0; if (nv < 1u) c.x = 0; }
-      }
+      uint4 c = values_of_group<V, ZZ>(d, key, nv);
       if (DELTA) {
         c.y += c.x; c.z += c.y; c.w += c.z;
         const u32 si = row_scan_incl(c.w);

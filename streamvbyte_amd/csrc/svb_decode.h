@@ -192,6 +192,41 @@ __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, i
   return total;
 }
 
+// ---- a group straight from registers (no LDS) ----------------------------------
+// bytes [o, o+4) of the 16-byte little-endian value d (o = 0..12), zero beyond
+__device__ __forceinline__ u32 bytes_at(const uint4& d, u32 o) {
+  const u32 i = o >> 2;
+  const u32 lo = i == 0 ? d.x : (i == 1 ? d.y : (i == 2 ? d.z : d.w));
+  const u32 hi = i == 0 ? d.y : (i == 1 ? d.z : (i == 2 ? d.w : 0u));
+  return __builtin_amdgcn_alignbyte(hi, lo, o);
+}
+// data bytes of the group coded by `key`, whose first nv (0..4) values exist
+template <int V>
+__device__ __forceinline__ u32 group_len(u32 key, u32 nv) {
+  u32 L = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) L += (u32)k < nv ? len_of<V>((key >> (2 * k)) & 3u) : 0u;
+  return L;
+}
+// The four values of a group whose data bytes start at byte 0 of d (the 16 bytes
+// loaded at the group's own byte address); absent values are zero.
+template <int V, bool ZZ>
+__device__ __forceinline__ uint4 values_of_group(const uint4& d, u32 key, u32 nv) {
+  u32 l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) l[k] = (u32)k < nv ? len_of<V>((key >> (2 * k)) & 3u) : 0u;
+  uint4 c;
+  c.x = bytes_at(d, 0) & (l[0] ? mask_of<V>(key & 3u) : 0u);
+  c.y = bytes_at(d, l[0]) & (l[1] ? mask_of<V>((key >> 2) & 3u) : 0u);
+  c.z = bytes_at(d, l[0] + l[1]) & (l[2] ? mask_of<V>((key >> 4) & 3u) : 0u);
+  c.w = bytes_at(d, l[0] + l[1] + l[2]) & (l[3] ? mask_of<V>((key >> 6) & 3u) : 0u);
+  if (ZZ) {
+    c = make_uint4(zz_dec(c.x), zz_dec(c.y), zz_dec(c.z), zz_dec(c.w));
+    if (nv < 4u) { c.w = 0; if (nv < 3u) c.z = 0; if (nv < 2u) c.y = 0; if (nv < 1u) c.x = 0; }
+  }
+  return c;
+}
+
 // Store group `first..first+3` of a stream of `count` values.
 __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, const uint4& v) {
   if (first + 4 <= count) {
