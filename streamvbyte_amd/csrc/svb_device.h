@@ -40,6 +40,7 @@ __device__ __forceinline__ u32 ld_u32(const u8* p) {
   __builtin_memcpy(&v, p, 4);
   return v;
 }
+__device__ __forceinline__ void st_u32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
 __device__ __forceinline__ uint4 ld_u128(const u8* p) {
   uint4 v;
   __builtin_memcpy(&v, p, 16);
