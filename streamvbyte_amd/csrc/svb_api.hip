@@ -78,6 +78,15 @@ inline T* ws_at(void* ws, size_t off) {
   return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off);
 }
 
+// Device fill by a kernel (see k_fill_u32): ptr 4-byte aligned, bytes a multiple of 4.
+int fill_u32(void* ptr, uint32_t value, size_t bytes, hipStream_t st) {
+  const unsigned long long n = bytes / 4;
+  const unsigned grid = (unsigned)std::min<unsigned long long>((n + kBlock - 1) / kBlock, 1024ull);
+  hipLaunchKernelGGL(k_fill_u32, dim3(grid ? grid : 1), dim3(kBlock), 0, st, static_cast<u32*>(ptr), value, (u64)n);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
 int check_ws(uint32_t count, void* ws, size_t ws_bytes) {
   if (!ws || ((uintptr_t)ws & 255u)) return SVBGPU_EWORKSPACE;
   if (ws_bytes < ws_layout(count).total) return SVBGPU_EWORKSPACE;
@@ -87,8 +96,7 @@ int check_ws(uint32_t count, void* ws, size_t ws_bytes) {
 // header + look-back words start every call at zero
 int clear_lookback(uint32_t count, void* ws, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  HIP_TRY(hipMemsetAsync(ws, 0, L.off_super_off, st));
-  return SVBGPU_OK;
+  return fill_u32(ws, 0u, L.off_super_off, st);
 }
 
 // ---- offset directory -------------------------------------------------------
@@ -278,7 +286,7 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
                   uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed, void* stream) {
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
-    if (d_consumed) HIP_TRY(hipMemsetAsync(d_consumed, 0, 8, S(stream)));
+    if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
     return SVBGPU_OK;
   }
   if (!d_in || !d_out) return SVBGPU_EINVAL;
@@ -306,7 +314,7 @@ int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t
                       void* stream) {
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
-    if (d_consumed) HIP_TRY(hipMemsetAsync(d_consumed, 0, 8, S(stream)));
+    if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
     return SVBGPU_OK;
   }
   if (!d_in || !d_out) return SVBGPU_EINVAL;
@@ -320,7 +328,7 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t co
                   uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_written, void* stream) {
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
-    if (d_written) HIP_TRY(hipMemsetAsync(d_written, 0, 8, S(stream)));
+    if (d_written) { int rc0 = fill_u32(d_written, 0u, 8, S(stream)); if (rc0) return rc0; }
     return SVBGPU_OK;
   }
   if (!d_in || !d_out) return SVBGPU_EINVAL;
@@ -338,7 +346,7 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t co
 int svbgpu_compressedbytes(int variant, unsigned flags, const uint32_t* d_in, uint32_t count,
                            uint32_t prev, uint64_t* d_bytes, void* stream) {
   if (bad_variant(variant) || bad_flags(flags) || !d_bytes) return SVBGPU_EINVAL;
-  HIP_TRY(hipMemsetAsync(d_bytes, 0, 8, S(stream)));
+  { int rc0 = fill_u32(d_bytes, 0u, 8, S(stream)); if (rc0) return rc0; }
   if (count == 0) return SVBGPU_OK;
   if (!d_in) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
@@ -356,12 +364,11 @@ int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32
   if (in_length == 0 || count == 0 || keylen > in_length) {
     // nothing to sum (reference src/streamvbyte_decode.c:91-111): the answer is known here
     const int r = (in_length == 0 || count == 0) ? in_length == (u64)count : 0;
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_ok), r, 1, S(stream)));
-    return SVBGPU_OK;
+    return fill_u32(d_ok, (uint32_t)r, 4, S(stream));
   }
   if (!d_in) return SVBGPU_EINVAL;
   WsHeader* h = ws_hdr(ws);
-  HIP_TRY(hipMemsetAsync(&h->accum, 0, 8, S(stream)));
+  { int rc0 = fill_u32(&h->accum, 0u, 8, S(stream)); if (rc0) return rc0; }
   const unsigned grid = stream_grid(((keylen + 15) / 16 + kBlock - 1) / kBlock, 2);
   if (variant == SVBGPU_1234)
     hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count,

@@ -4,6 +4,14 @@
 
 namespace svb {
 
+// Fill `n` 4-byte words with `value` (n small: header, status words, result
+// words).  A kernel of the library's own instead of hipMemsetAsync: memset
+// nodes recorded into a HIP graph were seen to write garbage from the second
+// replay on (ROCm 7.2), a kernel node replays like any other.
+__global__ void k_fill_u32(u32* __restrict__ p, u32 value, u64 n) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = value;
+}
+
 // Block-wide sum of a 64-bit value, result valid in thread 0.
 __device__ __forceinline__ u64 block_sum64(u64 x, u64* s_tmp) {
   x = wave_sum64(x);

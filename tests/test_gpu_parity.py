@@ -279,3 +279,33 @@ def test_batched_flag_combinations(torch_mod, codec, oracle, variant, flagbits):
     used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
     assert np.array_equal(used.cpu().numpy(), h_sizes)
     assert np.array_equal(to_np(back, np.uint32), values)
+
+
+def test_calls_capture_into_a_hip_graph(torch_mod, codec, oracle):
+    """The device API allocates nothing and never synchronises, so a sequence of
+    calls records into a HIP graph and replays on new data in the same buffers."""
+    from streamvbyte_amd import DELTA
+    torch = torch_mod
+    n = 50001
+    v0 = gen("width_mix", n, 1)
+    d_v = to_dev(torch, v0)
+    buf = torch.zeros(5 * n + 64, dtype=torch.uint8, device="cuda:0")
+    back = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            _, size = codec.encode(d_v, out=buf, flags=DELTA, prev=5)
+            ok = codec.validate(buf, 0, n)  # in_length is an argument, not device data: a wrong one must say 0
+            _, used = codec.decode(buf, n, out=back, flags=DELTA, prev=5)
+    for seed in (2, 3):
+        v = gen("width_mix", n, seed)
+        d_v.copy_(to_dev(torch, v))
+        graph.replay()
+        torch.cuda.synchronize()
+        expect = oracle.encode(V1234, v, True, 5)
+        assert int(size.item()) == expect.size and int(used.item()) == expect.size
+        assert np.array_equal(buf[: expect.size].cpu().numpy(), expect)
+        assert np.array_equal(to_np(back, np.uint32), v)
+        assert int(ok.item()) == 0
+    codec.check()
