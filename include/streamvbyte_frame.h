@@ -25,9 +25,10 @@
  *    32  the stream, then zero bytes up to the next multiple of 16
  *
  * All pointers are HOST pointers.  Page-locked buffers (svbframe_alloc_pinned,
- * hipHostMalloc, hipHostRegister) give overlapped copies; pageable buffers are
- * registered for the duration of a call when the system allows it and work
- * either way.  Functions return SVBFRAME_OK, a negative SVBFRAME_E* code, or a
+ * hipHostMalloc, hipHostRegister) give overlapped copies at PCIe speed;
+ * pageable buffers work too, through the runtime's staging copies (the library
+ * does not page-lock caller memory itself: locking and unlocking pages that
+ * other threads' buffers share is not safe).  Functions return SVBFRAME_OK, a negative SVBFRAME_E* code, or a
  * negative SVBGPU_E* code from streamvbyte_gpu.h; nothing is decoded on the CPU.
  */
 #ifndef INCLUDE_STREAMVBYTE_FRAME_H_

@@ -277,8 +277,8 @@ size_t svbgpu_workspace_bytes(uint32_t count) { return ws_layout(count).total; }
 int svbgpu_check_status(const void* d_workspace, void* stream) {
   if (!d_workspace) return SVBGPU_EWORKSPACE;
   u32 err = 0;
-  HIP_TRY(hipMemcpyAsync(&err, d_workspace, 4, hipMemcpyDeviceToHost, S(stream)));
   HIP_TRY(hipStreamSynchronize(S(stream)));
+  HIP_TRY(hipMemcpy(&err, d_workspace, 4, hipMemcpyDeviceToHost));
   return err ? SVBGPU_ESCAN : SVBGPU_OK;
 }
 
@@ -480,7 +480,10 @@ struct Ctx {
   void* b = nullptr;       size_t b_cap = 0;   // staged output
   uint64_t* d_res = nullptr;                    // 64 bytes of device results
   uint64_t* h_res = nullptr;                    // pinned mirror
+  uint8_t* stage[2] = {nullptr, nullptr};       // page-locked staging chunks for pageable caller memory
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};  // the chunk's last copy has ended
 };
+constexpr size_t kStageChunk = 4u << 20;
 std::mutex g_pool_mu;
 std::vector<Ctx*> g_pool;
 
@@ -502,15 +505,25 @@ Ctx* ctx_acquire() {
   HIP_OR_DIE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_OR_DIE(hipMalloc(&c->d_res, 64));
   HIP_OR_DIE(hipHostMalloc(&c->h_res, 64, hipHostMallocDefault));
+  for (int k = 0; k < 2; ++k) {
+    HIP_OR_DIE(hipHostMalloc(&c->stage[k], kStageChunk, hipHostMallocDefault));
+    HIP_OR_DIE(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
+  }
   return c;
 }
 void ctx_release(Ctx* c) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   g_pool.push_back(c);
 }
+// One host-pointer call drives the HIP runtime at a time.  The calls stay
+// re-entrant (own context, own stream, own buffers), but eight threads inside
+// the runtime at once ended in aborts from within it; every call ends with a
+// synchronisation anyway, so the device sees the same sequence of work.
+std::mutex g_host_api_mu;
 struct CtxGuard {
+  std::lock_guard<std::mutex> serial;
   Ctx* c;
-  CtxGuard() : c(ctx_acquire()) {}
+  CtxGuard() : serial(g_host_api_mu), c(ctx_acquire()) {}
   ~CtxGuard() { ctx_release(c); }
 };
 
@@ -532,14 +545,78 @@ bool is_device_ptr(const void* p) {
   return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
 }
 
+// Page-locked host memory HIP knows about (hipHostMalloc, hipHostRegister).
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// Host <-> device copies of the host-pointer API.  HIP never sees a pageable
+// caller pointer: such memory moves through the context's own page-locked
+// chunks with plain memcpy on this thread, two chunks in flight.  (Handing
+// pageable pointers of many threads to hipMemcpyAsync at once ended in heap
+// corruption and aborts inside the runtime; callers' buffers share pages.)
+// copy_in returns when the source has been read, copy_out when the destination
+// holds the data; both keep the order of the context's stream.
+int copy_in(Ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+  if (is_pinned_host(h_src)) {
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    return SVBGPU_OK;
+  }
+  size_t i = 0;
+  for (size_t off = 0; off < bytes; off += kStageChunk, ++i) {
+    const size_t len = std::min(kStageChunk, bytes - off);
+    const int k = (int)(i & 1);
+    if (i >= 2) HIP_TRY(hipEventSynchronize(c->stage_ev[k]));
+    std::memcpy(c->stage[k], static_cast<const uint8_t*>(h_src) + off, len);
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(d_dst) + off, c->stage[k], len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->stage_ev[k], c->stream));
+  }
+  // the chunks are free again once the stream has passed them
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SVBGPU_OK;
+}
+int copy_out(Ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+  if (is_pinned_host(h_dst)) {
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SVBGPU_OK;
+  }
+  const size_t nchunks = (bytes + kStageChunk - 1) / kStageChunk;
+  for (size_t i = 0; i <= nchunks; ++i) {
+    if (i < nchunks) {
+      const size_t off = i * kStageChunk, len = std::min(kStageChunk, bytes - off);
+      HIP_TRY(hipMemcpyAsync(c->stage[i & 1], static_cast<const uint8_t*>(d_src) + off, len, hipMemcpyDeviceToHost,
+                             c->stream));
+      HIP_TRY(hipEventRecord(c->stage_ev[i & 1], c->stream));
+    }
+    if (i >= 1) {  // chunk i-1 has landed: hand it to the caller while chunk i is on its way
+      const size_t off = (i - 1) * kStageChunk, len = std::min(kStageChunk, bytes - off);
+      HIP_TRY(hipEventSynchronize(c->stage_ev[(i - 1) & 1]));
+      std::memcpy(static_cast<uint8_t*>(h_dst) + off, c->stage[(i - 1) & 1], len);
+    }
+  }
+  return SVBGPU_OK;
+}
+#define COPY_OR_DIE(expr)                 \
+  do {                                    \
+    int rc_ = (expr);                     \
+    if (rc_) die("host copy", rc_);       \
+  } while (0)
+
 uint64_t fetch_u64(Ctx* c, const uint64_t* d_word) {
   HIP_OR_DIE(hipMemcpyAsync(c->h_res, d_word, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_OR_DIE(hipStreamSynchronize(c->stream));
   return c->h_res[0];
 }
 void check_scan(Ctx* c) {
-  int rc = svbgpu_check_status(c->ws, c->stream);
-  if (rc) die("device scan", rc);
+  HIP_OR_DIE(hipMemcpyAsync(c->h_res + 2, c->ws, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_OR_DIE(hipStreamSynchronize(c->stream));
+  if (reinterpret_cast<const uint32_t*>(c->h_res + 2)[0]) die("device scan", SVBGPU_ESCAN);
 }
 
 size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t count, uint8_t* out,
@@ -551,7 +628,7 @@ size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t coun
   const uint32_t* d_in = in;
   if (!is_device_ptr(in)) {
     grow(c->a, c->a_cap, (size_t)count * 4);
-    HIP_OR_DIE(hipMemcpyAsync(c->a, in, (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    COPY_OR_DIE(copy_in(c, c->a, in, (size_t)count * 4));
     d_in = static_cast<const uint32_t*>(c->a);
   }
   const bool out_dev = is_device_ptr(out);
@@ -564,10 +641,7 @@ size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t coun
   if (rc) die("encode", rc);
   const uint64_t n = fetch_u64(c, c->d_res);
   check_scan(c);
-  if (!out_dev) {
-    HIP_OR_DIE(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_OR_DIE(hipStreamSynchronize(c->stream));
-  }
+  if (!out_dev) COPY_OR_DIE(copy_out(c, out, d_out, n));
   return (size_t)n;
 }
 
@@ -584,16 +658,15 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
     // The stream's length is not known up front: stage the keys, let the
     // device sum them, then stage exactly the data bytes they promise.
     grow(c->a, c->a_cap, keylen + 16);
-    HIP_OR_DIE(hipMemcpyAsync(c->a, in, keylen, hipMemcpyHostToDevice, c->stream));
+    COPY_OR_DIE(copy_in(c, c->a, in, keylen));
     rc = build_directory(variant, static_cast<const uint8_t*>(c->a), count, c->ws, c->stream);
     if (rc) die("decode (key scan)", rc);
     const uint64_t total = fetch_u64(c, &ws_hdr(c->ws)->total_data);
     if (c->a_cap < keylen + total + 16) {
       grow(c->a, c->a_cap, keylen + total + 16);
-      HIP_OR_DIE(hipMemcpyAsync(c->a, in, keylen + total, hipMemcpyHostToDevice, c->stream));
+      COPY_OR_DIE(copy_in(c, c->a, in, keylen + total));
     } else {
-      HIP_OR_DIE(hipMemcpyAsync(static_cast<uint8_t*>(c->a) + keylen, in + keylen, total,
-                                hipMemcpyHostToDevice, c->stream));
+      COPY_OR_DIE(copy_in(c, static_cast<uint8_t*>(c->a) + keylen, in + keylen, total));
     }
     d_in = static_cast<const uint8_t*>(c->a);
   } else {
@@ -608,8 +681,7 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
   }
   rc = run_decode(variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream);
   if (rc) die("decode", rc);
-  if (!out_dev)
-    HIP_OR_DIE(hipMemcpyAsync(out, d_out, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream));
+  if (!out_dev) COPY_OR_DIE(copy_out(c, out, d_out, (size_t)count * 4));
   const uint64_t n = fetch_u64(c, c->d_res);
   if (flags & SVBGPU_DELTA) check_scan(c);
   return (size_t)n;
@@ -622,7 +694,7 @@ size_t size_any(int variant, const uint32_t* in, uint32_t count) {
   const uint32_t* d_in = in;
   if (!is_device_ptr(in)) {
     grow(c->a, c->a_cap, (size_t)count * 4);
-    HIP_OR_DIE(hipMemcpyAsync(c->a, in, (size_t)count * 4, hipMemcpyHostToDevice, c->stream));
+    COPY_OR_DIE(copy_in(c, c->a, in, (size_t)count * 4));
     d_in = static_cast<const uint32_t*>(c->a);
   }
   int rc = svbgpu_compressedbytes(variant, 0, d_in, count, 0, c->d_res, c->stream);
@@ -641,7 +713,7 @@ bool validate_any(int variant, const uint8_t* in, size_t in_length, uint32_t cou
   const uint8_t* d_in = in;
   if (!is_device_ptr(in)) {
     grow(c->a, c->a_cap, keylen + 16);
-    HIP_OR_DIE(hipMemcpyAsync(c->a, in, keylen, hipMemcpyHostToDevice, c->stream));
+    COPY_OR_DIE(copy_in(c, c->a, in, keylen));
     d_in = static_cast<const uint8_t*>(c->a);
   }
   int rc = svbgpu_validate(variant, d_in, in_length, count, reinterpret_cast<uint32_t*>(c->d_res + 1),
@@ -661,7 +733,7 @@ void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
   void* d_out = out;
   if (!in_dev) {
     grow(c->a, c->a_cap, n * 4);
-    HIP_OR_DIE(hipMemcpyAsync(c->a, in, n * 4, hipMemcpyHostToDevice, c->stream));
+    COPY_OR_DIE(copy_in(c, c->a, in, n * 4));
     d_in = c->a;
   }
   if (!out_dev) {
@@ -679,7 +751,7 @@ void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
                        (uint32_t)prev, c->stream);
   }
   if (rc) die("zigzag", rc);
-  if (!out_dev) HIP_OR_DIE(hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (!out_dev) COPY_OR_DIE(copy_out(c, out, d_out, n * 4));
   HIP_OR_DIE(hipStreamSynchronize(c->stream));
   if (mode == 3) check_scan(c);
 }

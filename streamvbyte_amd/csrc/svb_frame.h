@@ -25,28 +25,6 @@ static_assert(sizeof(FrameHdr) == SVBFRAME_HEADER_BYTES, "frame header is 32 byt
 
 inline uint64_t round16(uint64_t x) { return (x + 15) & ~(uint64_t)15; }
 
-// Page-lock a caller's host range for the lifetime of the object, unless HIP
-// already knows the range.  Failing to lock is not an error: copies from
-// pageable memory work, they only overlap less.
-struct HostPin {
-  void* p = nullptr;
-  HostPin(const void* ptr, size_t bytes) {
-    if (!ptr || !bytes) return;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;
-    (void)hipGetLastError();
-    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
-      p = const_cast<void*>(ptr);
-    else
-      (void)hipGetLastError();
-  }
-  ~HostPin() {
-    if (p) (void)hipHostUnregister(p);
-  }
-  HostPin(const HostPin&) = delete;
-  HostPin& operator=(const HostPin&) = delete;
-};
-
 // kFrameSlots contexts with their buffers sized up front (growing a buffer
 // later would free memory that queued work still uses).
 struct FrameSlots {
@@ -55,6 +33,7 @@ struct FrameSlots {
   hipEvent_t up[kFrameSlots] = {};    // the slot's host-to-device copy has ended
   hipEvent_t down[kFrameSlots] = {};  // the slot's device-to-host copy has ended
   int n = 0;
+  bool pinned_in = false, pinned_out = false;  // the caller's buffers are page-locked
   int init(size_t a_bytes, size_t b_bytes, uint32_t max_count) {
     for (n = 0; n < kFrameSlots; ++n) {
       c[n] = ctx_acquire();
@@ -78,8 +57,11 @@ struct FrameSlots {
   // for the previous frame's), so that a frame's upload ends early and its
   // kernels and download overlap the next frames' uploads; left alone, the
   // slots' copies share the link, end together and the two directions take turns.
+  // Pageable caller memory goes through the slot's own page-locked chunks
+  // (copy_in / copy_out of svb_api.hip, which block): correct, not overlapped.
   int copy_up(size_t i, void* dst, const void* src, size_t bytes) {
     const int s = (int)(i % kFrameSlots), p = (int)((i + kFrameSlots - 1) % kFrameSlots);
+    if (!pinned_in) return copy_in(c[s], dst, src, bytes);
     if (i) HIP_TRY(hipStreamWaitEvent(c[s]->stream, up[p], 0));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c[s]->stream));
     HIP_TRY(hipEventRecord(up[s], c[s]->stream));
@@ -87,10 +69,16 @@ struct FrameSlots {
   }
   int copy_down(size_t i, void* dst, const void* src, size_t bytes) {
     const int s = (int)(i % kFrameSlots), p = (int)((i + kFrameSlots - 1) % kFrameSlots);
+    if (!pinned_out) return copy_out(c[s], dst, src, bytes);
     if (i) HIP_TRY(hipStreamWaitEvent(c[s]->stream, down[p], 0));
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c[s]->stream));
     HIP_TRY(hipEventRecord(down[s], c[s]->stream));
     return SVBGPU_OK;
+  }
+  int scan_status(int s) {  // error word of the slot's workspace (see svbgpu_check_status)
+    HIP_TRY(hipMemcpyAsync(c[s]->h_res + 2, c[s]->ws, 4, hipMemcpyDeviceToHost, c[s]->stream));
+    HIP_TRY(hipStreamSynchronize(c[s]->stream));
+    return reinterpret_cast<const uint32_t*>(c[s]->h_res + 2)[0] ? SVBGPU_ESCAN : SVBGPU_OK;
   }
   int drain() {
     int rc = SVBGPU_OK;
@@ -186,8 +174,10 @@ int svbframe_encode_many(const uint32_t* in, size_t n, uint32_t frame_values, in
   if (out_capacity < svbframe_max_bytes_many(n, frame_values)) return SVBFRAME_ECAPACITY;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   const size_t nframes = (n + frame_values - 1) / frame_values;
-  HostPin pin_in(in, n * 4), pin_out(out, out_capacity);
+  std::lock_guard<std::mutex> serial(g_host_api_mu);
   FrameSlots S;
+  S.pinned_in = is_pinned_host(in);
+  S.pinned_out = is_pinned_host(out);
   int rc = S.init((size_t)frame_values * 4, streamvbyte_max_compressedbytes(frame_values), frame_values);
   if (rc) return rc;
 
@@ -239,7 +229,7 @@ int svbframe_encode_many(const uint32_t* in, size_t n, uint32_t frame_values, in
   }
   const int rd = S.drain();
   if (!rc) rc = rd;
-  for (int s = 0; s < S.n && !rc; ++s) rc = svbgpu_check_status(S.c[s]->ws, S.c[s]->stream);
+  for (int s = 0; s < S.n && !rc; ++s) rc = S.scan_status(s);
   if (!rc) *written = off;
   return rc;
 }
@@ -270,8 +260,10 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
   if (total > out_capacity) return SVBFRAME_ECAPACITY;
   if (fr.empty()) return SVBFRAME_OK;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  HostPin pin_in(frames, bytes), pin_out(out, total * 4);
+  std::lock_guard<std::mutex> serial(g_host_api_mu);
   FrameSlots S;
+  S.pinned_in = is_pinned_host(frames);
+  S.pinned_out = is_pinned_host(out);
   int rc = S.init((size_t)max_stream + 16, (size_t)max_count * 4, max_count);
   if (rc) return rc;
 
@@ -306,7 +298,7 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
   }
   const int rd = S.drain();
   if (!rc) rc = rd;
-  for (int s = 0; s < S.n && !rc; ++s) rc = svbgpu_check_status(S.c[s]->ws, S.c[s]->stream);
+  for (int s = 0; s < S.n && !rc; ++s) rc = S.scan_status(s);
   return rc;
 }
 

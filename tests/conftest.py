@@ -37,3 +37,14 @@ def reference():
         return Reference()
     except FileNotFoundError:
         return None
+
+
+if os.environ.get("SVB_ABORT_TRACE"):
+    # diagnostic: native backtrace on SIGABRT / SIGSEGV (tools/native/abort_trace.c)
+    import ctypes
+    import subprocess
+    import tempfile
+    _so = os.path.join(tempfile.gettempdir(), "svb_abort_trace.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", _so,
+                           os.path.join(ROOT, "tools", "native", "abort_trace.c")])
+    ctypes.CDLL(_so).abort_trace_install()

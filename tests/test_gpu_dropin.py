@@ -5,6 +5,9 @@ import ctypes
 import numpy as np
 import pytest
 
+from oracle import V1234, V0124
+from util import GENERATORS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -146,3 +149,42 @@ def test_device_pointers_through_reference_names(svb, oracle):
     d_back = torch.zeros_like(d_v)
     used = lib.streamvbyte_decode(d_out.data_ptr(), d_back.data_ptr(), v.size)
     assert used == size and np.array_equal(d_back.cpu().numpy().view(np.uint32), v)
+
+
+def test_concurrent_callers(svb, oracle):
+    """The reference API is re-entrant (pure functions of their arguments): eight
+    threads calling every host-pointer function at once on their own buffers get
+    the answers they would get alone.  ctypes releases the GIL during the calls."""
+    import threading
+    errors = []
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(900 + t)
+            for i in range(12):
+                n = int(rng.integers(1, 60000))
+                v = GENERATORS[["width_mix", "sparse", "postings", "perf_c"][(t + i) % 4]](rng, n)
+                e = svb.streamvbyte_encode(v)
+                assert np.array_equal(e, oracle.encode(V1234, v)), ("encode", t, i)
+                out, used = svb.streamvbyte_decode(e, n)
+                assert used == e.size and np.array_equal(out, v), ("decode", t, i)
+                assert svb.streamvbyte_validate_stream(e, n) and not svb.streamvbyte_validate_stream(e[:-1], n)
+                assert svb.streamvbyte_compressedbytes(v) == e.size
+                d = svb.streamvbyte_delta_encode(v, prev=t)
+                assert np.array_equal(d, oracle.encode(V1234, v, True, t)), ("delta", t, i)
+                assert np.array_equal(svb.streamvbyte_delta_decode(d, n, prev=t)[0], v)
+                z = svb.streamvbyte_encode_0124(v)
+                assert np.array_equal(z, oracle.encode(V0124, v)) and np.array_equal(svb.streamvbyte_decode_0124(z, n)[0], v)
+                s = v.view(np.int32)
+                assert np.array_equal(svb.zigzag_delta_decode(svb.zigzag_delta_encode(s, -t), -t), s)
+                f = svb.frame_encode_many(v, 7000, flags=svb.DELTA)
+                assert np.array_equal(svb.frame_decode_many(f), v), ("frames", t, i)
+        except BaseException as exc:  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
