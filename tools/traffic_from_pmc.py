@@ -22,12 +22,13 @@ def per_kernel(path, counter):
     return {k: float(np.median([x for x in v if x >= 0.95 * max(v)])) for k, v in d.items()}
 
 
-f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(f) | set(w)):
-    fk, wk = f.get(k, 0.0), w.get(k, 0.0)
-    out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes": int((2 * fk + wk) * 1024)}
-json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, n = 2^28 (2^26 for the 0124 zigzag kernels), "
-                   "tools/microbench.py inputs; a kernel launched on several workloads is reported for the "
-                   "largest one (the delta decoders: deltas of full-width values, ~3.75 data bytes per value)",
-           "kernels": out}, sys.stdout, indent=1)
+if __name__ == "__main__":
+    f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        fk, wk = f.get(k, 0.0), w.get(k, 0.0)
+        out[k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "hbm_bytes": int((2 * fk + wk) * 1024)}
+    json.dump({"note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, n = 2^28 (2^26 for the 0124 zigzag kernels), "
+                       "tools/microbench.py inputs; a kernel launched on several workloads is reported for the "
+                       "largest one (the delta decoders: deltas of full-width values, ~3.75 data bytes per value)",
+               "kernels": out}, sys.stdout, indent=1)
