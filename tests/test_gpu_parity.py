@@ -309,3 +309,42 @@ def test_calls_capture_into_a_hip_graph(torch_mod, codec, oracle):
         assert np.array_equal(to_np(back, np.uint32), v)
         assert int(ok.item()) == 0
     codec.check()
+
+
+def test_device_api_errors_and_empty_inputs(torch_mod, codec):
+    """Error codes instead of faults: bad workspace, bad arguments; count == 0 everywhere."""
+    torch = torch_mod
+    lib = codec.lib
+    st = torch.cuda.current_stream().cuda_stream
+    v = torch.arange(5000, dtype=torch.int32, device="cuda:0")
+    buf = torch.zeros(5 * 5000 + 64, dtype=torch.uint8, device="cuda:0")
+    res = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    ws, wsb = codec.ws.data_ptr(), codec.ws_bytes
+    need = lib.svbgpu_workspace_bytes(5000)
+    # workspace: missing, misaligned, too small
+    assert lib.svbgpu_encode(0, 0, v.data_ptr(), 5000, buf.data_ptr(), 0, None, 0, res.data_ptr(), st) == -3
+    assert lib.svbgpu_encode(0, 0, v.data_ptr(), 5000, buf.data_ptr(), 0, ws + 8, wsb - 8, res.data_ptr(), st) == -3
+    assert lib.svbgpu_encode(0, 0, v.data_ptr(), 5000, buf.data_ptr(), 0, ws, need - 256, res.data_ptr(), st) == -3
+    assert lib.svbgpu_decode(0, 0, buf.data_ptr(), v.data_ptr(), 5000, 0, ws, need - 256, res.data_ptr(), st) == -3
+    # arguments
+    assert lib.svbgpu_encode(2, 0, v.data_ptr(), 5000, buf.data_ptr(), 0, ws, wsb, res.data_ptr(), st) == -1
+    assert lib.svbgpu_encode(0, 4, v.data_ptr(), 5000, buf.data_ptr(), 0, ws, wsb, res.data_ptr(), st) == -1
+    assert lib.svbgpu_encode(0, 0, None, 5000, buf.data_ptr(), 0, ws, wsb, res.data_ptr(), st) == -1
+    assert lib.svbgpu_decode(0, 0, None, v.data_ptr(), 5000, 0, ws, wsb, res.data_ptr(), st) == -1
+    assert lib.svbgpu_set_option(b"encode_tile", 3) == -1 and lib.svbgpu_set_option(b"no_such_knob", 1) == -1
+    assert lib.svbgpu_encode_batch(0, 0, None, None, None, None, None, None, 5, None, st) == -1
+    # count == 0: nothing is touched but the result words
+    res.fill_(77)
+    assert lib.svbgpu_encode(0, 0, None, 0, None, 0, None, 0, res.data_ptr(), st) == 0
+    assert lib.svbgpu_decode(0, 0, None, None, 0, 0, None, 0, res.data_ptr() + 8, st) == 0
+    assert lib.svbgpu_compressedbytes(0, 0, None, 0, 0, res.data_ptr() + 16, st) == 0
+    assert lib.svbgpu_encode_batch(0, 0, None, None, None, None, None, None, 0, None, st) == 0
+    torch.cuda.synchronize()
+    assert res[:3].tolist() == [0, 0, 0]
+    ok = codec.validate(buf, 0, 0)
+    assert int(ok.item()) == 1
+    assert int(codec.validate(buf, 5, 0).item()) == 0 and int(codec.validate(buf, 0, 5).item()) == 0
+    # still healthy afterwards
+    out, size = codec.encode(v)
+    dec, used = codec.decode(out, 5000)
+    assert torch.equal(dec, v) and int(used.item()) == int(size.item())
