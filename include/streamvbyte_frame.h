@@ -26,9 +26,9 @@
  *
  * All pointers are HOST pointers.  Page-locked buffers (svbframe_alloc_pinned,
  * hipHostMalloc, hipHostRegister) give overlapped copies at PCIe speed;
- * pageable buffers work too, through the runtime's staging copies (the library
- * does not page-lock caller memory itself: locking and unlocking pages that
- * other threads' buffers share is not safe).  Functions return SVBFRAME_OK, a negative SVBFRAME_E* code, or a
+ * pageable buffers work too, copied through page-locked chunks of the library's
+ * own (it never page-locks caller memory: pages are shared with other threads'
+ * buffers).  Functions return SVBFRAME_OK, a negative SVBFRAME_E* code, or a
  * negative SVBGPU_E* code from streamvbyte_gpu.h; nothing is decoded on the CPU.
  */
 #ifndef INCLUDE_STREAMVBYTE_FRAME_H_

@@ -40,7 +40,7 @@ struct FrameSlots {
       grow(c[n]->a, c[n]->a_cap, a_bytes);
       grow(c[n]->b, c[n]->b_cap, b_bytes);
       grow(c[n]->ws, c[n]->ws_cap, svbgpu_workspace_bytes(max_count));
-      if (hipMemsetAsync(c[n]->ws, 0, sizeof(WsHeader), c[n]->stream) != hipSuccess) {  // error word starts clear
+      if (fill_u32(c[n]->ws, 0u, sizeof(WsHeader), c[n]->stream) != SVBGPU_OK) {  // error word starts clear
         ctx_release(c[n]);
         return SVBGPU_EHIP;
       }
