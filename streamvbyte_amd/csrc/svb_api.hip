@@ -105,12 +105,11 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
   u32* super_sum = ws_at<u32>(ws, L.off_super_sum);
   u64* super_off = ws_at<u64>(ws, L.off_super_off);
+  const unsigned grid = stream_grid(L.n_super, 8);
   if (variant == SVBGPU_1234)
-    hipLaunchKernelGGL(k_key_sums<V1234>, dim3((unsigned)L.n_super), dim3(kBlock), 0, st, d_in, count,
-                       wt_rel, super_sum);
+    hipLaunchKernelGGL(k_key_sums<V1234>, dim3(grid), dim3(kBlock), 0, st, d_in, count, wt_rel, super_sum);
   else
-    hipLaunchKernelGGL(k_key_sums<V0124>, dim3((unsigned)L.n_super), dim3(kBlock), 0, st, d_in, count,
-                       wt_rel, super_sum);
+    hipLaunchKernelGGL(k_key_sums<V0124>, dim3(grid), dim3(kBlock), 0, st, d_in, count, wt_rel, super_sum);
   hipLaunchKernelGGL(k_scan_super, dim3(1), dim3(1024), 0, st, super_sum, super_off,
                      (u32)L.n_super, &ws_hdr(ws)->total_data);
   HIP_TRY(hipGetLastError());

@@ -65,13 +65,6 @@ __global__ __launch_bounds__(kBlock) void k_decode_batch(
 // quad.  Handles lists of 1..kRowMax values; longer ones loop in steps of 64.
 constexpr u32 kRowMax = 256;
 
-__device__ __forceinline__ u32 row_scan_incl(u32 x) {
-  x += dpp_zero<0x111, 0xF>(x);
-  x += dpp_zero<0x112, 0xF>(x);
-  x += dpp_zero<0x114, 0xF>(x);
-  x += dpp_zero<0x118, 0xF>(x);
-  return x;
-}
 // value of lane 15 of the caller's row
 __device__ __forceinline__ u32 row_last(u32 x, int lane) { return __shfl(x, (lane & 48) | 15, 64); }
 

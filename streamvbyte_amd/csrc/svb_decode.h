@@ -9,7 +9,7 @@
 namespace svb {
 
 // ---------------------------------------------------------------------------
-// k_key_sums: one workgroup per super tile (64 wave tiles = 16384 keys).
+// k_key_sums: one super tile (64 wave tiles = 16384 keys) per workgroup and round.
 // Thread t, round i reads the 16 keys at i*4096 + 16*t, so every 16 lanes cover
 // one wave tile; a 16-lane reduction gives the wave tile's data bytes.  Wave 0
 // then scans the 64 sums: wt_rel[] = data offset of each wave tile inside its
@@ -22,8 +22,10 @@ __global__ __launch_bounds__(kBlock) void k_key_sums(const u8* __restrict__ in, 
   __shared__ u32 s_sum[kSuperWt];
   const u64 keylen = ((u64)count + 3) >> 2;
   const u64 n_wt = (keylen + kWtKeys - 1) / kWtKeys;
-  const u64 key_base = (u64)blockIdx.x * (kSuperWt * kWtKeys);
   const int t = threadIdx.x;
+  const u64 n_super = (n_wt + kSuperWt - 1) / kSuperWt;
+  for (u64 sb = blockIdx.x; sb < n_super; sb += gridDim.x) {
+  const u64 key_base = sb * (kSuperWt * kWtKeys);
 
   uint4 k[4];
 #pragma unroll
@@ -44,20 +46,19 @@ __global__ __launch_bounds__(kBlock) void k_key_sums(const u8* __restrict__ in, 
       const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
       s += word_len<V>(mask_codes(w[d], nvd), nvd);
     }
-    // reduce over the 16 lanes that share a wave tile
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    if ((t & 15) == 0) s_sum[i * 16 + (t >> 4)] = s;
+    // reduce over the 16 lanes (one DPP row) that share a wave tile
+    s = row_scan_incl(s);
+    if ((t & 15) == 15) s_sum[i * 16 + (t >> 4)] = s;
   }
   __syncthreads();
   if (t < 64) {
     const u32 x = s_sum[t];
     const u32 incl = wave_scan_incl(x, t);
-    const u64 wt = (u64)blockIdx.x * kSuperWt + t;
+    const u64 wt = sb * kSuperWt + t;
     if (wt < n_wt) wt_rel[wt] = incl - x;
-    if (t == 63) super_sum[blockIdx.x] = incl;
+    if (t == 63) super_sum[sb] = incl;
+  }
+  __syncthreads();  // s_sum is reused by the next super tile
   }
 }
 

@@ -78,6 +78,14 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 x, int /*lane*/) {
   x += dpp_zero<0x143, 0xC>(x);  // row_bcast:31 into rows 2 and 3
   return x;
 }
+// Inclusive prefix sum inside each row of 16 lanes.
+__device__ __forceinline__ u32 row_scan_incl(u32 x) {
+  x += dpp_zero<0x111, 0xF>(x);
+  x += dpp_zero<0x112, 0xF>(x);
+  x += dpp_zero<0x114, 0xF>(x);
+  x += dpp_zero<0x118, 0xF>(x);
+  return x;
+}
 // Value of lane 63 (wave-uniform).
 __device__ __forceinline__ u32 wave_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
 // Value of the previous lane; lane 0 receives `first`.
