@@ -54,6 +54,9 @@ int svbgpu_device_ok(void);
 /* Tuning knobs (process-wide, not thread-safe against running calls):
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
  *                               encoder carries through the look-back (default 4)
+ *   "decode_shortcut" = 0|1     1 (default): the plain decoder copies wave tiles
+ *                               (1024 values) whose keys are all zero straight
+ *                               from their data bytes; 0: one code path for all
  *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
  *                               streaming passes; 1: single pass with look-back
  *   "debug_ablate" = bits       timing-only diagnostics, results become wrong

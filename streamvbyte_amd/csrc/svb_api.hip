@@ -116,13 +116,19 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   return SVBGPU_OK;
 }
 
+int g_decode_shortcut = 1;  // plain decoder: shortcut for wave tiles of all-zero keys, see svbgpu_set_option
+
 template <int V, bool ZZ>
 void launch_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, void* ws,
                    uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, 7);
-  hipLaunchKernelGGL((k_decode<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
-                     ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed);
+  if (g_decode_shortcut)
+    hipLaunchKernelGGL((k_decode<V, ZZ, true>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
+                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed);
+  else
+    hipLaunchKernelGGL((k_decode<V, ZZ, false>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
+                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed);
 }
 template <int V, bool ZZ>
 void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
@@ -257,6 +263,10 @@ int svbgpu_set_option(const char* name, int value) {
   if (!name) return SVBGPU_EINVAL;
   if (!std::strcmp(name, "debug_ablate")) {
     g_debug = (unsigned)value;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "decode_shortcut")) {
+    g_decode_shortcut = value != 0;
     return SVBGPU_OK;
   }
   if (!std::strcmp(name, "delta_decode_lookback")) {

@@ -169,9 +169,27 @@ __device__ __forceinline__ uint4 extract_group(u32 entry, u32 shift, const u8* s
 // One wave tile, keys -> values: lane ends up with the (up to) 4 groups
 // j*64+lane, j = 0..3, of the wave tile whose keys it holds blocked in `w`.
 // Values past `nints` are returned as zero.  Returns the tile's data bytes.
-template <int V, bool ZZ>
+template <int V, bool ZZ, bool SHORTCUT = true>
 __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, int lane, WaveLds& S,
                                                uint4 (&v)[4]) {
+  // A full wave tile whose 256 keys are all zero (every value below 256; dense
+  // posting-list gaps are the common case, and the reference has the same
+  // shortcut, src/streamvbytedelta_x64_decode.c:87-100): 1234 data bytes ARE the
+  // values, group j*64+lane is the dword at byte 4*(j*64+lane); 0124 has no data
+  // bytes at all.  No scan, no LDS.
+  if (SHORTCUT && nints == kWtInts && __ballot(w != 0u) == 0ull) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (V == V1234) {
+        const u32 d = ld_u32(dp + 4u * (j * 64 + lane));
+        r = make_uint4(d & 0xFFu, (d >> 8) & 0xFFu, (d >> 16) & 0xFFu, d >> 24);
+        if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
+      }
+      v[j] = r;
+    }
+    return V == V1234 ? (u32)kWtInts : 0u;
+  }
   const u32 nv = nints > 16u * lane ? min(nints - 16u * lane, 16u) : 0u;
   const u32 total = scan_keys_to_entries<V>(w, nv, lane, S.ent);
   const u32 shift = stage_span(dp, total, lane, S.data);
@@ -244,7 +262,7 @@ __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, cons
 // grid) with the next tile's keys and offset prefetched.  No inter-workgroup
 // dependency: data offsets come from the directory built by k_key_sums /
 // k_scan_super.  HBM traffic per value: 0.25 (keys) + dbar (data) + 4 (out).
-template <int V, bool ZZ>
+template <int V, bool ZZ, bool SHORTCUT>
 __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
                                                    u32* __restrict__ out, u32 count,
                                                    const u64* __restrict__ super_off,
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
     uint4 v[4];
-    const u32 total = decode_wavetile<V, ZZ>(w, nints, data_base + doff, lane, S, v);
+    const u32 total = decode_wavetile<V, ZZ, SHORTCUT>(w, nints, data_base + doff, lane, S, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) store_group(out, int0 + 4u * (j * 64 + lane), count, v[j]);
     if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;

@@ -198,6 +198,19 @@ __device__ __forceinline__ void store_head(u8* image, u32 first_dword, u32 p, u3
 template <int V, bool FULL>
 __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&g)[4], u32 nints,
                                                int lane, EncWaveLds& S, u8* dst, u8* kdst) {
+  // A full wave tile whose 256 keys are all zero (every value below 256 for
+  // 1234, every value zero for 0124; the mirror image of the decoder's
+  // shortcut): a group's data bytes are the low bytes of its four values, one
+  // dword at byte 4 * (j*64+lane).  No scan, no LDS.
+  if (FULL && __ballot((gi_key(g[0]) | gi_key(g[1]) | gi_key(g[2]) | gi_key(g[3])) != 0u) == 0ull) {
+    if (V == V1234) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        st_u32(dst + 4u * (j * 64 + lane), x[j].x | (x[j].y << 8) | (x[j].z << 16) | (x[j].w << 24));
+    }
+    st_u32(kdst + 4 * lane, 0u);
+    return V == V1234 ? (u32)kWtInts : 0u;
+  }
   u64 packed = 0;  // 4 x 16-bit group lengths, one per j
 #pragma unroll
   for (int j = 0; j < 4; ++j) packed |= (u64)gi_total(g[j]) << (16 * j);

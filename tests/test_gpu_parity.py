@@ -348,3 +348,37 @@ def test_device_api_errors_and_empty_inputs(torch_mod, codec):
     out, size = codec.encode(v)
     dec, used = codec.decode(out, 5000)
     assert torch.equal(dec, v) and int(used.item()) == int(size.item())
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+def test_all_small_wave_tiles(torch_mod, codec, oracle, variant):
+    """Wave tiles (1024 values) whose keys are all zero take a shortcut in the decoders
+    and encoders; mix them with ordinary tiles, with tiles that miss the condition
+    by one value, and with a short last tile."""
+    from streamvbyte_amd import DELTA, ZIGZAG
+    rng = np.random.default_rng(77)
+    hi = 256 if variant == V1234 else 1  # values whose code is 0
+    for n in (1024, 4096 + 7, 20 * 1024, 20 * 1024 + 1000, 70000):
+        v = GENERATORS["width_mix"](rng, n)
+        for t in range(0, n, 1024):
+            kind = (t // 1024) % 4
+            if kind in (0, 1):  # all small
+                v[t:t + 1024] = rng.integers(0, hi, size=min(1024, n - t), dtype=np.uint32)
+            if kind == 1 and t + 1024 <= n:  # ... except one value somewhere
+                v[t + int(rng.integers(0, 1024))] = 0x12345
+        for flags, prev in ((0, 0), (DELTA, 3), (ZIGZAG, 0)):
+            src = np.cumsum(v.astype(np.uint64)).astype(np.uint32) if flags == DELTA else v
+            if flags == DELTA:
+                src = (src + np.uint32(3)).astype(np.uint32)  # deltas against prev = 3 are exactly v
+            expect = _expected_stream(oracle, variant, flags, src, prev)
+            out, size = codec.encode(to_dev(torch_mod, src), variant=variant, flags=flags, prev=prev)
+            codec.check()
+            assert int(size.item()) == expect.size, (n, flags)
+            assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, flags)
+            for lookback in ((0, 1) if flags == DELTA else (0,)):
+                codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
+                dec, used = codec.decode(dev_stream(torch_mod, expect, misalign=n % 3), n, variant=variant, flags=flags, prev=prev)
+                codec.check()
+                codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+                assert int(used.item()) == expect.size
+                assert np.array_equal(to_np(dec, np.uint32), src), (n, flags, lookback)

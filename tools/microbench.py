@@ -43,6 +43,12 @@ enc_out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8,
 if want("decode"):
     ops["decode_plan"] = (lambda: codec.decode_plan(stream, n), 0.25 * n)
     ops["decode_run"] = (lambda: codec.decode_run(stream, n, out), (4.25 + dbar) * n)
+
+    def no_shortcut():
+        codec.lib.svbgpu_set_option(b"decode_shortcut", 0)
+        codec.decode_run(stream, n, out)
+        codec.lib.svbgpu_set_option(b"decode_shortcut", 1)
+    ops["decode_run_noshortcut"] = (no_shortcut, (4.25 + dbar) * n)
 def enc_with(qw, f):
     def g():
         codec.lib.svbgpu_set_option(b"encode_tile", qw)
