@@ -66,25 +66,31 @@ def test_missing_library_is_an_error(monkeypatch):
         L.load()
 
 
-def _build_c_caller(tmp_path):
+C_PROGRAMS = [("tests", "c", "dropin_roundtrip.c"), ("examples", "example.c"), ("examples", "writeseq.c")]
+
+
+def _build_c_caller(tmp_path, source=C_PROGRAMS[0]):
     import streamvbyte_amd
-    exe = str(tmp_path / "dropin_roundtrip")
+    exe = str(tmp_path / os.path.splitext(source[-1])[0])
     libdir = os.path.dirname(streamvbyte_amd.LIB_PATH)
     cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", INCLUDE,
-           os.path.join(ROOT, "tests", "c", "dropin_roundtrip.c"), "-o", exe,
+           os.path.join(ROOT, *source), "-o", exe,
            "-L", libdir, "-l:libstreamvbyte.so.2", f"-Wl,-rpath,{libdir}",
            "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return exe
 
 
-def test_plain_c_caller_compiles_and_links(tmp_path):
-    """A C99 program using only the reference's headers builds against the library."""
-    _build_c_caller(tmp_path)
+@pytest.mark.parametrize("source", C_PROGRAMS, ids=lambda s: s[-1])
+def test_plain_c_caller_compiles_and_links(tmp_path, source):
+    """C99 programs using only the headers under include/ build against the library."""
+    _build_c_caller(tmp_path, source)
 
 
 @pytest.mark.gpu
-def test_plain_c_caller_runs(tmp_path):
-    exe = _build_c_caller(tmp_path)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+@pytest.mark.parametrize("source", C_PROGRAMS, ids=lambda s: s[-1])
+def test_plain_c_caller_runs(tmp_path, source):
+    exe = _build_c_caller(tmp_path, source)
+    args = [exe, str(tmp_path / "seq.bin")] if source[-1] == "writeseq.c" else [exe]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
