@@ -4,8 +4,8 @@
 A batch of independent streams is pushed through a three-stage pipeline
 (hipMemcpyAsync H2D -> kernels -> hipMemcpyAsync D2H) on three HIP streams with
 a ring of device buffers, so that copies in both directions overlap the
-kernels.  Prints one JSON line; the numbers are PCIe-bound and are quoted in
-DESIGN.md next to the device-resident ones, never as the bench `value`.
+kernels.  Prints one JSON line; the numbers are PCIe-bound: a companion to the
+device-resident rates of bench.py, never its `value`.
 
     python tools/e2e_bench.py [--log2n 24] [--streams 16] [--ring 3]
 """
