@@ -61,6 +61,7 @@ def test_encode_matches_oracle(torch_mod, codec, oracle, variant, kind):
         assert np.array_equal(got, expect), (kind, n, np.flatnonzero(got != expect)[:5])
         if mis:
             assert (buf[:mis].cpu().numpy() == 0xAB).all()  # nothing written in front of out
+        assert (buf[mis + expect.size:].cpu().numpy() == 0xAB).all(), (kind, n)  # nor behind the stream
 
 
 @pytest.mark.parametrize("kind", ["postings", "full", "width_mix"])
@@ -382,3 +383,31 @@ def test_all_small_wave_tiles(torch_mod, codec, oracle, variant):
                 codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
                 assert int(used.item()) == expect.size
                 assert np.array_equal(to_np(dec, np.uint32), src), (n, flags, lookback)
+
+
+def test_decoders_write_exactly_count_values(torch_mod, codec, oracle):
+    """The reference never writes past out[n-1] (src/streamvbyte_decode.c:74-86); neither
+    may any decoder here, nor in front of out."""
+    from streamvbyte_amd import DELTA, ZIGZAG
+    torch = torch_mod
+    guard = 64
+    for n in (1, 3, 5, 1023, 1025, 4099, 16385, 70001):
+        v = gen("width_mix", n, 40 + n)
+        for variant, flags in ((V1234, 0), (V0124, 0), (V1234, DELTA), (V0124, ZIGZAG), (V1234, DELTA | ZIGZAG)):
+            s = _expected_stream(oracle, variant, flags, v, 9 if flags & DELTA else 0)
+            for lookback in ((0, 1) if flags & DELTA else (0,)):
+                big = torch.full((n + 2 * guard,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+                codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
+                codec.decode(dev_stream(torch, s), n, out=big[guard:guard + n], variant=variant, flags=flags,
+                             prev=9 if flags & DELTA else 0)
+                codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+                h = big.cpu().numpy().view(np.uint32)
+                assert np.array_equal(h[guard:guard + n], v), (n, variant, flags)
+                assert (h[:guard] == 0x5A5A5A5A).all() and (h[guard + n:] == 0x5A5A5A5A).all(), (n, variant, flags)
+        # zigzag_delta_decode and the plain maps
+        zz = oracle.zigzag_delta_encode(v.view(np.int32), -4)
+        big = torch.full((n + 2 * guard,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+        codec.zigzag(to_dev(torch, zz), "delta_decode", -4, out=big[guard:guard + n])
+        h = big.cpu().numpy().view(np.uint32)
+        assert np.array_equal(h[guard:guard + n], v)
+        assert (h[:guard] == 0x5A5A5A5A).all() and (h[guard + n:] == 0x5A5A5A5A).all(), n
