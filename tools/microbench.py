@@ -92,6 +92,12 @@ if want("delta"):
     sm, zm = codec.encode(values, flags=svb.DELTA)
     sm = sm.clone()
     ops["delta_decode_mixed"] = (lambda: codec.decode(sm, n, out=out, flags=svb.DELTA), (int(zm.item()) + 4.0 * n))
+
+    def ddm_lookback():
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+        codec.decode(sm, n, out=out, flags=svb.DELTA)
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+    ops["delta_decode_mixed_lookback"] = (ddm_lookback, (int(zm.item()) + 4.0 * n))
 if want("zz"):
     n4 = min(n, 1 << 26)
     g = torch.Generator(device=dev); g.manual_seed(9)
