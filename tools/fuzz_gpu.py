@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity: sizes, value distributions, variants, flags, misalignments,
+single stream, batched and host-pointer calls.  python tools/fuzz_gpu.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import streamvbyte_amd as svb
+from oracle import Oracle
+from util import GENERATORS, to_dev, to_np, dev_stream
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.default_rng(seed)
+oracle = Oracle()
+codec = svb.DeviceCodec(1 << 21)
+kinds = list(GENERATORS)
+
+
+def expected(variant, flags, v, prev):
+    if flags & 2:
+        s = v.view(np.int32)
+        sp = prev - (1 << 32) if prev >= (1 << 31) else prev
+        pre = oracle.zigzag_delta_encode(s, sp) if flags & 1 else oracle.zigzag_encode(s)
+        return oracle.encode(variant, pre)
+    return oracle.encode(variant, v, bool(flags & 1), prev)
+
+
+def blocky(n):
+    """mix of 1024-blocks of different character (exercises the per-wave-tile shortcuts)"""
+    v = np.empty(n, dtype=np.uint32)
+    for t in range(0, n, 1024):
+        m = min(1024, n - t)
+        v[t:t + m] = GENERATORS[kinds[int(rng.integers(len(kinds)))]](rng, m) if rng.random() < 0.5 else rng.integers(0, 256, size=m, dtype=np.uint32)
+    return v
+
+
+t_end, it = time.time() + budget, 0
+while time.time() < t_end:
+    it += 1
+    n = int(rng.choice([rng.integers(1, 70), rng.integers(1, 5000), rng.integers(1, 300000), rng.integers(900000, 1200000)]))
+    v = blocky(n) if rng.random() < 0.4 else GENERATORS[kinds[int(rng.integers(len(kinds)))]](rng, n)
+    variant, flags = int(rng.integers(2)), int(rng.integers(4))
+    prev = int(rng.integers(0, 1 << 32)) if flags & 1 else 0
+    qw = int(rng.choice([1, 2, 4]))
+    lb = int(rng.integers(2))
+    tag = (seed, it, n, variant, flags, prev, qw, lb)
+    exp = expected(variant, flags, v, prev)
+    codec.lib.svbgpu_set_option(b"encode_tile", qw)
+    codec.lib.svbgpu_set_option(b"delta_decode_lookback", lb)
+    mis = int(rng.integers(0, 4))
+    buf = torch.full((mis + svb.streamvbyte_max_compressedbytes(n),), 0xCD, dtype=torch.uint8, device="cuda:0")
+    _, size = codec.encode(to_dev(torch, v), out=buf[mis:], variant=variant, flags=flags, prev=prev)
+    codec.check()
+    assert int(size.item()) == exp.size, ("size",) + tag
+    h = buf.cpu().numpy()
+    assert np.array_equal(h[mis:mis + exp.size], exp), ("bytes",) + tag
+    assert (h[:mis] == 0xCD).all() and (h[mis + exp.size:] == 0xCD).all(), ("stray write",) + tag
+    assert int(codec.compressedbytes(to_dev(torch, v), variant=variant, flags=flags, prev=prev).item()) == exp.size, ("cb",) + tag
+    d_s = dev_stream(torch, exp, misalign=int(rng.integers(0, 4)))
+    assert int(codec.validate(d_s, exp.size, n, variant=variant).item()) == 1, ("validate",) + tag
+    if exp.size > (n + 3) // 4:
+        assert int(codec.validate(d_s, exp.size - 1, n, variant=variant).item()) == 0, ("validate-1",) + tag
+    dec, used = codec.decode(d_s, n, variant=variant, flags=flags, prev=prev)
+    codec.check()
+    assert int(used.item()) == exp.size and np.array_equal(to_np(dec, np.uint32), v), ("decode",) + tag
+    if it % 5 == 0 and not (flags & 2):  # host-pointer API (reference names)
+        if variant == 0 and flags & 1:
+            e = svb.streamvbyte_delta_encode(v, prev); o, u = svb.streamvbyte_delta_decode(e, n, prev)
+        elif variant == 0:
+            e = svb.streamvbyte_encode(v); o, u = svb.streamvbyte_decode(e, n)
+        elif not flags:
+            e = svb.streamvbyte_encode_0124(v); o, u = svb.streamvbyte_decode_0124(e, n)
+        else:
+            e = None
+        if e is not None:
+            assert np.array_equal(e, exp) and u == exp.size and np.array_equal(o, v), ("host api",) + tag
+    if it % 7 == 0:  # frames
+        fv = int(rng.integers(1, 60000))
+        fr = svb.frame_encode_many(v, fv, variant=variant, flags=flags)
+        assert np.array_equal(svb.frame_decode_many(fr), v), ("frames", fv) + tag
+codec.lib.svbgpu_set_option(b"encode_tile", 4)
+codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+print(f"fuzz ok: {it} cases, seed {seed}")
