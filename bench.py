@@ -373,7 +373,22 @@ def main():
                                           "decode_unfused_GBps": round(4.0 * n4 / ms_uf / 1e6, 1),
                                           "decode_roofline_frac": round((4.25 + d4) * n4 / ms_d / 1e6 / HBM_PEAK_GBS, 4),
                                           "encode_roofline_frac": round((4.25 + d4) * n4 / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
-        del gr, s4, tmp
+        # the same gradients as float32: quantise -> zigzag -> encode_0124 and back in one pass each
+        step = 1.0 / 64.0
+        xf = gr.to(torch.float32) * step
+        sq, zq = codec.quantize_encode(xf, 1.0 / step, variant=svb.V0124)
+        okq = bool(int(zq.item()) == sz4 and torch.equal(sq[:sz4], s4[:sz4]))
+        of = torch.empty(n4, dtype=torch.float32, device=device)
+        ms_qe, _ = event_ms(torch, lambda: codec.quantize_encode(xf, 1.0 / step, out=enc_out, variant=svb.V0124), it)
+        ms_dd, _ = event_ms(torch, lambda: codec.decode_dequantize(s4, n4, step, out=of, variant=svb.V0124), it)
+        okq &= bool(torch.equal(of, xf))
+        ms_da, _ = event_ms(torch, lambda: codec.decode_dequantize(s4, n4, step, out=of, accumulate=True, variant=svb.V0124), it)
+        extra["zigzag_0124_gradients"]["quantized_float32"] = {
+            "parity": okq, "quantize_encode_GBps": round(4.0 * n4 / ms_qe / 1e6, 1),
+            "decode_dequantize_GBps": round(4.0 * n4 / ms_dd / 1e6, 1),
+            "decode_dequantize_accumulate_GBps": round(4.0 * n4 / ms_da / 1e6, 1),
+            "accumulate_roofline_frac": round((8.25 + d4) * n4 / ms_da / 1e6 / HBM_PEAK_GBS, 4)}
+        del gr, s4, tmp, xf, of, sq
         # validate (0.25 B/value) and exact size (4 B/value) on the main stream
         ms_v, _ = event_ms(torch, lambda: codec.validate(stream, size, n), it)
         ms_s, _ = event_ms(torch, lambda: codec.compressedbytes(values), it)

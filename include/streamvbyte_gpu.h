@@ -101,6 +101,24 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t *d_in, uint32_t co
                   uint8_t *d_out, uint32_t prev, void *d_workspace, size_t workspace_bytes,
                   uint64_t *d_written, void *stream);
 
+/* Quantised floats (gradient compression: quantise -> zigzag -> encode, and back).
+ * No counterpart in the reference, whose callers run these steps as separate
+ * passes over memory around zigzag_encode / streamvbyte_encode_0124
+ * (src/streamvbyte_zigzag.c:3-11, src/streamvbyte_0124_encode.c:96-113); here
+ * they ride on the codec's own load and store.
+ *   svbgpu_quantize_encode:    q[i] = (int32) nearest-even(d_in[i] * scale), then
+ *                              exactly svbgpu_encode(variant, SVBGPU_ZIGZAG, q, ...)
+ *   svbgpu_decode_dequantize:  q = svbgpu_decode(variant, SVBGPU_ZIGZAG, ...), then
+ *                              d_out[i] = (float)q[i] * scale, or d_out[i] += ... when
+ *                              accumulate != 0 (summing several workers' chunks)
+ * Products beyond the int32 range saturate. */
+int svbgpu_quantize_encode(int variant, const float *d_in, uint32_t count, float scale,
+                           uint8_t *d_out, void *d_workspace, size_t workspace_bytes,
+                           uint64_t *d_written, void *stream);
+int svbgpu_decode_dequantize(int variant, const uint8_t *d_in, float *d_out, uint32_t count,
+                             float scale, int accumulate, void *d_workspace,
+                             size_t workspace_bytes, uint64_t *d_consumed, void *stream);
+
 /* Device-pointer form of streamvbyte_compressedbytes / _0124 (reference
  * include/streamvbyte.h:47,55); with SVBGPU_DELTA / SVBGPU_ZIGZAG the size the
  * matching svbgpu_encode call would produce.  *d_bytes receives the size. */

@@ -238,6 +238,33 @@ class DeviceCodec:
                    "svbgpu_decode")
         return out, self.res[1:2]
 
+    def quantize_encode(self, values, scale, out=None, variant=V0124):
+        """float32 tensor -> stream of zigzag(round(values * scale)); returns (out_bytes, size_tensor[1])."""
+        torch = self.torch
+        n = values.numel()
+        assert n <= self.max_count and values.is_contiguous() and values.dtype == torch.float32
+        if out is None:
+            out = torch.empty(streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_quantize_encode(variant, values.data_ptr(), n, scale, out.data_ptr(),
+                                                   self.ws.data_ptr(), self.ws_bytes, self._res_ptr(0), self._stream()),
+                   "svbgpu_quantize_encode")
+        return out, self.res[0:1]
+
+    def decode_dequantize(self, stream, count, scale, out=None, accumulate=False, variant=V0124):
+        """stream -> float32 tensor (int value * scale), optionally added to `out`."""
+        torch = self.torch
+        assert count <= self.max_count and stream.is_contiguous()
+        if out is None:
+            assert not accumulate
+            out = torch.empty(count, dtype=torch.float32, device=self.device)
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode_dequantize(variant, stream.data_ptr(), out.data_ptr(), count, scale,
+                                                     int(accumulate), self.ws.data_ptr(), self.ws_bytes,
+                                                     self._res_ptr(1), self._stream()), "svbgpu_decode_dequantize")
+        return out, self.res[1:2]
+
     def decode_plan(self, stream, count, variant=V1234):
         with self.torch.cuda.device(self.device):
             _check(self.lib.svbgpu_decode_plan(variant, stream.data_ptr(), count, self.ws.data_ptr(),

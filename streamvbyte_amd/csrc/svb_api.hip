@@ -125,10 +125,10 @@ void launch_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, void* w
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, 7);
   if (g_decode_shortcut)
     hipLaunchKernelGGL((k_decode<V, ZZ, true>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
-                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed);
+                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed, 0u);
   else
     hipLaunchKernelGGL((k_decode<V, ZZ, false>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
-                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed);
+                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed, 0u);
 }
 template <int V, bool ZZ>
 void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
@@ -191,7 +191,7 @@ size_t g_ws_bytes_hint = 0;
 unsigned g_debug = 0;  // timing-only ablations (wrong results!), see svbgpu_set_option
 int g_encode_qw = 4;  // wave tiles per wave in k_encode (1, 2 or 4); see svbgpu_set_option
 
-template <int V, bool D, bool Z, int QW>
+template <int V, bool D, bool Z, int QW, bool QUANT = false>
 void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                       uint64_t* d_written, hipStream_t st) {
   const WsLayout L = ws_layout(count);
@@ -204,10 +204,10 @@ void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint
   u64* stamps = (g_debug & 16u) && g_ws_bytes_hint >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
   if (full_tiles)
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true>), dim3(stream_grid(full_tiles, QW > 2 || V != V1234 ? 4 : 5)), dim3(kBlock),
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT>), dim3(stream_grid(full_tiles, QW > 2 || V != V1234 ? 4 : 5)), dim3(kBlock),
                        0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, g_debug, stamps);
   if (ragged)  // the one tile that runs past the end of the stream: same look-back words
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false>), dim3(1), dim3(kBlock), 0, st, d_in, count, full_tiles,
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT>), dim3(1), dim3(kBlock), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, g_debug, stamps);
 }
 template <int V, bool D, bool Z>
@@ -349,6 +349,62 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t co
   if (rc) return rc;
   g_ws_bytes_hint = ws_bytes;
   DISPATCH_VDZ(launch_encode, variant, flags, d_in, count, d_out, prev, ws, d_written, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float scale, uint8_t* d_out,
+                           void* ws, size_t ws_bytes, uint64_t* d_written, void* stream) {
+  if (bad_variant(variant)) return SVBGPU_EINVAL;
+  if (count == 0) {
+    if (d_written) { int rc0 = fill_u32(d_written, 0u, 8, S(stream)); if (rc0) return rc0; }
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = clear_lookback(count, ws, S(stream));
+  if (rc) return rc;
+  uint32_t bits;
+  std::memcpy(&bits, &scale, 4);
+  const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
+  if (variant == SVBGPU_1234)
+    launch_encode_qw<V1234, false, true, 4, true>(in, count, d_out, bits, ws, d_written, S(stream));
+  else
+    launch_encode_qw<V0124, false, true, 4, true>(in, count, d_out, bits, ws, d_written, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_decode_dequantize(int variant, const uint8_t* d_in, float* d_out, uint32_t count, float scale,
+                             int accumulate, void* ws, size_t ws_bytes, uint64_t* d_consumed, void* stream) {
+  if (bad_variant(variant)) return SVBGPU_EINVAL;
+  if (count == 0) {
+    if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = build_directory(variant, d_in, count, ws, S(stream));
+  if (rc) return rc;
+  uint32_t bits;
+  std::memcpy(&bits, &scale, 4);
+  const WsLayout L = ws_layout(count);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, 7);
+  u32* out = reinterpret_cast<u32*>(d_out);
+  u64* so = ws_at<u64>(ws, L.off_super_off);
+  u32* wr = ws_at<u32>(ws, L.off_wt_rel);
+  hipStream_t st = S(stream);
+  if (variant == SVBGPU_1234) {
+    if (accumulate) hipLaunchKernelGGL((k_decode<V1234, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
+    else            hipLaunchKernelGGL((k_decode<V1234, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
+  } else {
+    if (accumulate) hipLaunchKernelGGL((k_decode<V0124, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
+    else            hipLaunchKernelGGL((k_decode<V0124, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
+  }
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

@@ -262,12 +262,15 @@ __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, cons
 // grid) with the next tile's keys and offset prefetched.  No inter-workgroup
 // dependency: data offsets come from the directory built by k_key_sums /
 // k_scan_super.  HBM traffic per value: 0.25 (keys) + dbar (data) + 4 (out).
-template <int V, bool ZZ, bool SHORTCUT>
+// OUT: 0 = the integers; 1 = float32 (int32)value * scale (dequantise fused into the
+// store); 2 = the same added to what out already holds (dequantise-accumulate).
+// scale travels as the bits of `aux`.
+template <int V, bool ZZ, bool SHORTCUT, int OUT = 0>
 __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
                                                    u32* __restrict__ out, u32 count,
                                                    const u64* __restrict__ super_off,
                                                    const u32* __restrict__ wt_rel,
-                                                   u64* __restrict__ consumed) {
+                                                   u64* __restrict__ consumed, u32 aux) {
   __shared__ WaveLds s_lds[kWaves];
   const int lane = lane_id(), wave = wave_id();
   WaveLds& S = s_lds[wave];
@@ -298,7 +301,30 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
     uint4 v[4];
     const u32 total = decode_wavetile<V, ZZ, SHORTCUT>(w, nints, data_base + doff, lane, S, v);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) store_group(out, int0 + 4u * (j * 64 + lane), count, v[j]);
+    for (int j = 0; j < 4; ++j) {
+      const u64 first = int0 + 4u * (j * 64 + lane);
+      uint4 r = v[j];
+      if (OUT != 0) {
+        const float scale = __uint_as_float(aux);
+        // __fmul_rn / __fadd_rn: product and sum are rounded separately, never fused
+        float f[4] = {__fmul_rn((float)(int)r.x, scale), __fmul_rn((float)(int)r.y, scale),
+                      __fmul_rn((float)(int)r.z, scale), __fmul_rn((float)(int)r.w, scale)};
+        if (OUT == 2) {
+          const float* acc = reinterpret_cast<const float*>(out);
+          if (first + 4 <= count) {
+            float4 a;
+            __builtin_memcpy(&a, acc + first, 16);
+            f[0] = __fadd_rn(f[0], a.x); f[1] = __fadd_rn(f[1], a.y); f[2] = __fadd_rn(f[2], a.z); f[3] = __fadd_rn(f[3], a.w);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (first + k < count) f[k] = __fadd_rn(f[k], acc[first + k]);
+          }
+        }
+        r = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+      }
+      store_group(out, first, count, r);
+    }
     if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;
     if (wt_n >= n_wt) break;
     wt = wt_n;

@@ -323,7 +323,10 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // is a second single-workgroup launch of the FULL=false instantiation on the
 // same stream, continuing the same ticket and look-back words.
 // QW = wave tiles per wave; the workgroup's tile is 4*QW wave tiles.
-template <int V, bool DELTA, bool ZZ, int QW, bool FULL>
+// QUANT: the input holds float32; every value becomes (int32)rintf(x * scale) first
+// (scale travels as the bits of `prev`, which only DELTA uses otherwise) -- the
+// quantise step of gradient compression fused into the encoder's load.
+template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false>
 __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
@@ -373,6 +376,17 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         x[q][j] = load_group(in, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count);
+  }
+  if (QUANT) {
+    const float scale = __uint_as_float(prev);
+    auto q1 = [scale](u32 bits) -> u32 { return (u32)(int)rintf(__fmul_rn(__uint_as_float(bits), scale)); };
+#pragma unroll
+    for (int q = 0; q < QW; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4& c = x[q][j];
+        c = make_uint4(q1(c.x), q1(c.y), q1(c.z), q1(c.w));
+      }
   }
   if (DELTA) {
     // previous value of the wave's first element, then neighbours by lane shuffles

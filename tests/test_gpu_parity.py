@@ -411,3 +411,31 @@ def test_decoders_write_exactly_count_values(torch_mod, codec, oracle):
         h = big.cpu().numpy().view(np.uint32)
         assert np.array_equal(h[guard:guard + n], v)
         assert (h[:guard] == 0x5A5A5A5A).all() and (h[guard + n:] == 0x5A5A5A5A).all(), n
+
+
+@pytest.mark.parametrize("variant", [V0124, V1234])
+def test_quantized_floats_fused(torch_mod, codec, oracle, variant):
+    """quantise -> zigzag -> encode and decode -> un-zigzag -> dequantise(-accumulate) in one
+    pass each equal the same steps done one after the other (numpy float32 + oracle)."""
+    torch = torch_mod
+    rng = np.random.default_rng(8)
+    for n in (1, 5, 1023, 4096, 16384 + 3, 100003, 300000):
+        x = (rng.standard_normal(n) * rng.choice([0.3, 3.0, 300.0])).astype(np.float32)
+        x[rng.random(n) < 0.3] = 0.0
+        scale = np.float32(rng.choice([1.0, 7.5, 0.125]))
+        q = np.rint(x * scale).astype(np.int32)  # float32 product, round half to even: what the kernel does
+        expect = oracle.encode(variant, oracle.zigzag_encode(q))
+        d_x = torch.from_numpy(x).cuda()
+        out, size = codec.quantize_encode(d_x, float(scale), variant=variant)
+        codec.check()
+        assert int(size.item()) == expect.size, (n,)
+        assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n,)
+        step = np.float32(1.0) / scale
+        want = q.astype(np.float32) * step
+        dec, used = codec.decode_dequantize(dev_stream(torch, expect), n, float(step), variant=variant)
+        assert int(used.item()) == expect.size
+        assert np.array_equal(dec.cpu().numpy(), want), (n,)
+        acc0 = rng.standard_normal(n).astype(np.float32)
+        acc = torch.from_numpy(acc0.copy()).cuda()
+        codec.decode_dequantize(dev_stream(torch, expect), n, float(step), out=acc, accumulate=True, variant=variant)
+        assert np.array_equal(acc.cpu().numpy(), acc0 + want), (n,)
