@@ -78,6 +78,30 @@ while time.time() < t_end:
         fv = int(rng.integers(1, 60000))
         fr = svb.frame_encode_many(v, fv, variant=variant, flags=flags)
         assert np.array_equal(svb.frame_decode_many(fr), v), ("frames", fv) + tag
+    if it % 11 == 0:  # batched entry points
+        ns = int(rng.integers(1, 400))
+        top = int(rng.choice([8, 300, 5000]))
+        counts = rng.integers(0, top, size=ns).astype(np.uint32)
+        prevs = rng.integers(0, 1 << 32, size=ns, dtype=np.uint64).astype(np.uint32)
+        voff = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.int64)
+        cap = np.array([svb.streamvbyte_max_compressedbytes(int(c)) for c in counts], dtype=np.int64)
+        boff = np.concatenate([[0], np.cumsum(cap)]).astype(np.int64)
+        vals = blocky(int(voff[-1])) if voff[-1] else np.zeros(0, dtype=np.uint32)
+        d_vals = to_dev(torch, vals) if vals.size else torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        d_voff, d_boff = torch.from_numpy(voff[:-1].copy()).cuda(), torch.from_numpy(boff[:-1].copy()).cuda()
+        d_counts, d_prevs = to_dev(torch, counts), to_dev(torch, prevs)
+        bbuf = torch.zeros(int(boff[-1]) + 16, dtype=torch.uint8, device="cuda:0")
+        sizes = codec.encode_batch(d_vals, d_voff, bbuf, d_boff, d_counts, d_prevs, variant=variant, flags=flags)
+        hs, hb = sizes.cpu().numpy(), bbuf.cpu().numpy()
+        for k in range(ns):
+            lv = vals[voff[k]:voff[k + 1]]
+            e = expected(variant, flags, lv, int(prevs[k]) if flags & 1 else 0)
+            assert hs[k] == e.size and np.array_equal(hb[boff[k]:boff[k] + e.size], e), ("batch encode", k, int(counts[k])) + tag
+        back = torch.full_like(d_vals, 0x7B7B7B7B)
+        used = codec.decode_batch(bbuf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+        assert np.array_equal(used.cpu().numpy(), hs), ("batch used",) + tag
+        if vals.size:
+            assert np.array_equal(to_np(back, np.uint32), vals), ("batch decode",) + tag
 codec.lib.svbgpu_set_option(b"encode_tile", 4)
 codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
 print(f"fuzz ok: {it} cases, seed {seed}")
