@@ -153,6 +153,9 @@ int svbgpu_zigzag_delta_decode(const uint32_t *d_in, int32_t *d_out, size_t n, i
  * streamvbyte_max_compressedbytes(d_counts[s]) bytes for stream s and
  * d_sizes[s] receives the bytes written; for decode d_sizes[s] (optional)
  * receives the bytes consumed.
+ * A stream is handled by one 16-lane row (up to 256 values) or one wavefront,
+ * which suits streams of up to some 10^5 values; give longer ones to the
+ * single-stream calls above, which spread one stream over the whole device.
  */
 int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t *d_values,
                         const uint64_t *d_value_off, uint8_t *d_bytes, const uint64_t *d_byte_off,
