@@ -365,10 +365,6 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
     for (int q = 0; q < QW; ++q) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[q][j] = src[(u32)lane + (u32)(q * 256 + j * 64)];
-      if ((dbg & 32u) && (q & 1)) {  // experiment: at most two wave tiles of loads in flight per wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
   } else {
 #pragma unroll

@@ -69,7 +69,6 @@ if want("ablate"):
     ops["encode_nolookback"] = (dbg_with(1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_nopass2"] = (dbg_with(2, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_idle11us"] = (dbg_with(5, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
-    ops["encode_batched_loads"] = (dbg_with(32, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_neither"] = (dbg_with(3, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
 if want("encode"):
     for qw in (1, 2, 4):
