@@ -83,3 +83,26 @@ def test_large_stream(oracle, count, variant, delta):
     assert torch.equal(back, v)
     del back, buf, v, codec
     torch.cuda.empty_cache()
+
+
+def test_zigzag_maps_beyond_2_to_32():
+    """zigzag_encode / zigzag_decode take a size_t length (reference include/streamvbyte_zigzag.h:14,24)."""
+    import torch
+    import streamvbyte_amd as svb
+    n = (1 << 32) + 7
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4 * n * 4 + (4 << 30):
+        pytest.skip("not enough device memory")
+    codec = svb.DeviceCodec(1024)
+    v = _values(torch, n, 5)
+    v[-7:] = torch.tensor([-1, 1, -2, 2, 0, -(1 << 31), (1 << 31) - 1], dtype=torch.int32, device="cuda:0")
+    zz = codec.zigzag(v, "encode")
+    expect_tail = [1, 2, 3, 4, 0, 0xFFFFFFFF - (1 << 32), 0xFFFFFFFE - (1 << 32)]
+    assert zz[-7:].tolist() == expect_tail
+    ref = (v << 1) ^ (v >> 31)
+    assert torch.equal(zz, ref)
+    del ref
+    back = codec.zigzag(zz, "decode")
+    assert torch.equal(back, v)
+    del back, zz, v, codec
+    torch.cuda.empty_cache()
