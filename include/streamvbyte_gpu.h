@@ -59,6 +59,9 @@ int svbgpu_device_ok(void);
  *                               from their data bytes; 0: one code path for all
  *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
  *                               streaming passes; 1: single pass with look-back
+ *   "zigzag_piece" = n          values per device scan of the host-pointer
+ *                               zigzag_delta_decode (default 2^31; longer arrays
+ *                               go in pieces)
  *   "debug_ablate" = bits       timing-only diagnostics, results become wrong
  * Apart from "debug_ablate", results never depend on a knob, only speed. */
 int svbgpu_set_option(const char *name, int value);

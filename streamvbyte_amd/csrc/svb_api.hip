@@ -116,6 +116,7 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   return SVBGPU_OK;
 }
 
+size_t g_zigzag_piece = 1u << 31;  // values per device scan of the host-pointer zigzag_delta_decode
 int g_decode_shortcut = 1;  // plain decoder: shortcut for wave tiles of all-zero keys, see svbgpu_set_option
 
 template <int V, bool ZZ>
@@ -264,6 +265,11 @@ int svbgpu_set_option(const char* name, int value) {
   if (!name) return SVBGPU_EINVAL;
   if (!std::strcmp(name, "debug_ablate")) {
     g_debug = (unsigned)value;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "zigzag_piece")) {
+    if (value < 1) return SVBGPU_EINVAL;
+    g_zigzag_piece = (size_t)value;
     return SVBGPU_OK;
   }
   if (!std::strcmp(name, "decode_shortcut")) {
@@ -816,10 +822,23 @@ void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
   }
   int rc;
   if (mode == 3) {
-    if (n > 0xFFFFFFFFull) die("zigzag_delta_decode (N >= 2^32)", SVBGPU_EINVAL);
-    grow(c->ws, c->ws_cap, svbgpu_workspace_bytes((uint32_t)n));
-    rc = svbgpu_zigzag_delta_decode(static_cast<const uint32_t*>(d_in), static_cast<int32_t*>(d_out),
-                                    n, prev, c->ws, c->ws_cap, c->stream);
+    // The device scan counts in 32 bits; a longer array (N is a size_t in the
+    // reference, include/streamvbyte_zigzag.h:29) goes in pieces, each seeded with
+    // the last value of the piece before it.
+    const size_t piece = g_zigzag_piece;
+    grow(c->ws, c->ws_cap, svbgpu_workspace_bytes((uint32_t)std::min(n, piece)));
+    rc = SVBGPU_OK;
+    for (size_t off = 0; off < n && !rc; off += piece) {
+      const size_t len = std::min(piece, n - off);
+      if (off) {
+        HIP_OR_DIE(hipMemcpyAsync(c->h_res + 3, static_cast<int32_t*>(d_out) + off - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OR_DIE(hipStreamSynchronize(c->stream));
+        prev = reinterpret_cast<const int32_t*>(c->h_res + 3)[0];
+        check_scan(c);
+      }
+      rc = svbgpu_zigzag_delta_decode(static_cast<const uint32_t*>(d_in) + off, static_cast<int32_t*>(d_out) + off,
+                                      len, prev, c->ws, c->ws_cap, c->stream);
+    }
   } else {
     rc = zigzag_launch(mode, static_cast<const uint32_t*>(d_in), static_cast<uint32_t*>(d_out), n,
                        (uint32_t)prev, c->stream);

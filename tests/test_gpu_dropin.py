@@ -188,3 +188,17 @@ def test_concurrent_callers(svb, oracle):
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_zigzag_delta_decode_in_pieces(svb, oracle):
+    """Arrays longer than one device scan (2^31 values by default) go in pieces seeded with the
+    previous piece's last value; with a small piece size the same path runs on a small array."""
+    lib = svb.load()
+    rng = np.random.default_rng(3)
+    v = rng.integers(-(1 << 31), 1 << 31, size=5003, dtype=np.int64).astype(np.int32)
+    zz = oracle.zigzag_delta_encode(v, -77)
+    assert lib.svbgpu_set_option(b"zigzag_piece", 1000) == 0
+    try:
+        assert np.array_equal(svb.zigzag_delta_decode(zz, -77), v)
+    finally:
+        lib.svbgpu_set_option(b"zigzag_piece", 2**31 - 1)
