@@ -84,6 +84,57 @@ int svbframe_encode_many(const uint32_t *in, size_t n, uint32_t frame_values, in
 int svbframe_decode_many(const uint8_t *frames, size_t bytes, uint32_t *out, size_t out_capacity,
                          size_t *n_values);
 
+/*
+ * List frames: many independent lists (posting lists, one stream each) per
+ * frame, with a directory, for callers who would otherwise write one tiny
+ * frame per list.  List i holds values[list_start[i] .. list_start[i+1]) and is
+ * coded as a stream of its own (with SVBGPU_DELTA seeded with 0), exactly what
+ * the reference's streamvbyte_encode / _0124 / delta_encode writes for it.
+ *
+ * Layout, little endian, every part starts at a multiple of 16 bytes:
+ *     0  u32  magic  'S' 'V' 'B' 'L'
+ *     4  u8   version (1)
+ *     5  u8   variant
+ *     6  u8   flags
+ *     7  u8   0
+ *     8  u32  n_lists
+ *    12  u32  0
+ *    16  u64  n_values      sum of the counts
+ *    24  u64  payload_bytes sum of the sizes
+ *    32  u32  count[n_lists]   values per list, zero padded to 16 bytes
+ *        u32  size[n_lists]    stream bytes per list, zero padded to 16 bytes
+ *        the streams, back to back in list order, zero padded to 16 bytes
+ * A list holds at most SVBFRAME_LIST_MAX_VALUES values, a frame at most
+ * SVBFRAME_MAX_LISTS lists.
+ */
+#define SVBFRAME_LIST_MAX_VALUES (1u << 29)
+#define SVBFRAME_MAX_LISTS (1u << 20)
+
+/* Worst-case size of what svbframe_encode_lists writes. */
+size_t svbframe_lists_max_bytes(size_t n_values, size_t n_lists, uint32_t frame_values);
+
+/* Encode n_lists lists as consecutive list frames.  A frame takes whole lists
+ * while it holds at most frame_values values (a longer list gets a frame of its
+ * own).  list_start has n_lists + 1 non-decreasing entries, list_start[0] is
+ * the index of the first value in `values`. */
+int svbframe_encode_lists(const uint32_t *values, const uint64_t *list_start, size_t n_lists,
+                          uint32_t frame_values, int variant, unsigned flags, uint8_t *out,
+                          size_t out_capacity, size_t *written);
+
+/* Walk consecutive list frames (headers only): frames, lists, values.  Host only. */
+int svbframe_scan_lists(const uint8_t *frames, size_t bytes, size_t *n_frames, size_t *n_lists,
+                        size_t *n_values);
+
+/* Decode consecutive list frames: values[0 .. *n_values) and list_start[0 ..
+ * *n_lists] (list_start[0] = 0).  values_capacity counts values, lists_capacity
+ * lists (list_start has room for lists_capacity + 1 entries).  The host checks
+ * every directory, the device every list against its directory entry before
+ * anything is decoded (SVBFRAME_EBADFRAME / SVBFRAME_EINVALID).  With values ==
+ * NULL only *n_lists and *n_values are computed. */
+int svbframe_decode_lists(const uint8_t *frames, size_t bytes, uint32_t *values,
+                          size_t values_capacity, uint64_t *list_start, size_t lists_capacity,
+                          size_t *n_lists, size_t *n_values);
+
 /* Page-locked host memory for the buffers above. */
 void *svbframe_alloc_pinned(size_t bytes);
 void svbframe_free_pinned(void *p);

@@ -186,6 +186,44 @@ def frame_decode_many(frames):
     return out
 
 
+def frame_scan_lists(frames):
+    """(frames, lists, values) of consecutive list frames."""
+    f = _np(frames, np.uint8)
+    nf, nl, nv = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    _check_frame(load().svbframe_scan_lists(_ptr(f), f.size, C.addressof(nf), C.addressof(nl), C.addressof(nv)),
+                 "svbframe_scan_lists")
+    return nf.value, nl.value, nv.value
+
+
+def frame_encode_lists(values, list_start, frame_values, variant=V1234, flags=0):
+    """Lists values[list_start[i]:list_start[i+1]] -> consecutive list frames (uint8 array)."""
+    lib = load()
+    v = _np(values, np.uint32)
+    ls = _np(list_start, np.uint64)
+    n_lists = max(ls.size - 1, 0)
+    n_values = int(ls[-1] - ls[0]) if ls.size else 0
+    cap = lib.svbframe_lists_max_bytes(n_values, n_lists, frame_values)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    written = C.c_size_t(0)
+    _check_frame(lib.svbframe_encode_lists(_ptr(v), _ptr(ls), n_lists, frame_values, variant, flags, _ptr(out), cap,
+                                           C.addressof(written)), "svbframe_encode_lists")
+    return out[:written.value].copy()
+
+
+def frame_decode_lists(frames):
+    """consecutive list frames -> (uint32 values, uint64 list_start with one entry more than lists)."""
+    lib = load()
+    f = _np(frames, np.uint8)
+    nl, nv = C.c_size_t(0), C.c_size_t(0)
+    _check_frame(lib.svbframe_decode_lists(_ptr(f), f.size, None, 0, None, 0, C.addressof(nl), C.addressof(nv)),
+                 "svbframe_decode_lists")
+    out = np.empty(max(nv.value, 1), dtype=np.uint32)
+    ls = np.zeros(nl.value + 1, dtype=np.uint64)
+    _check_frame(lib.svbframe_decode_lists(_ptr(f), f.size, _ptr(out), nv.value, _ptr(ls), nl.value, C.addressof(nl),
+                                           C.addressof(nv)), "svbframe_decode_lists")
+    return out[:nv.value], ls
+
+
 class DeviceCodec:
     """Device-pointer API on torch tensors (include/streamvbyte_gpu.h).
 

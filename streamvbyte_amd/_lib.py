@@ -54,6 +54,10 @@ SIGNATURES = {
     "svbframe_scan": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "svbframe_encode_many": (C.c_int, [vp, C.c_size_t, C.c_uint32, C.c_int, C.c_uint, vp, C.c_size_t, vp]),
     "svbframe_decode_many": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp]),
+    "svbframe_lists_max_bytes": (C.c_size_t, [C.c_size_t, C.c_size_t, C.c_uint32]),
+    "svbframe_encode_lists": (C.c_int, [vp, vp, C.c_size_t, C.c_uint32, C.c_int, C.c_uint, vp, C.c_size_t, vp]),
+    "svbframe_scan_lists": (C.c_int, [vp, C.c_size_t, vp, vp, vp]),
+    "svbframe_decode_lists": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, vp]),
     "svbframe_alloc_pinned": (vp, [C.c_size_t]),
     "svbframe_free_pinned": (None, [vp]),
 }

@@ -21,6 +21,7 @@
 #include "svb_encode.h"
 #include "svb_misc.h"
 #include "svb_batch.h"
+#include "svb_lists.h"
 
 using namespace svb;
 
@@ -550,6 +551,9 @@ struct Ctx {
   void* ws = nullptr;      size_t ws_cap = 0;
   void* a = nullptr;       size_t a_cap = 0;   // staged input
   void* b = nullptr;       size_t b_cap = 0;   // staged output
+  void* p = nullptr;       size_t p_cap = 0;   // list frames: the packed streams
+  void* dir = nullptr;     size_t dir_cap = 0; // list frames: the directory on the device
+  void* hdir = nullptr;    size_t hdir_cap = 0;  // ... and its page-locked host image
   uint64_t* d_res = nullptr;                    // 64 bytes of device results
   uint64_t* h_res = nullptr;                    // pinned mirror
   uint8_t* stage[2] = {nullptr, nullptr};       // page-locked staging chunks for pageable caller memory
@@ -604,6 +608,14 @@ void grow(void*& p, size_t& cap, size_t need) {
   if (p) HIP_OR_DIE(hipFree(p));
   size_t n = need + need / 4 + 4096;
   HIP_OR_DIE(hipMalloc(&p, n));
+  cap = n;
+}
+
+void grow_pinned(void*& p, size_t& cap, size_t need) {
+  if (need <= cap) return;
+  if (p) HIP_OR_DIE(hipHostFree(p));
+  size_t n = need + need / 4 + 4096;
+  HIP_OR_DIE(hipHostMalloc(&p, n, hipHostMallocDefault));
   cap = n;
 }
 
@@ -895,3 +907,4 @@ void zigzag_delta_decode(const uint32_t* in, int32_t* out, size_t N, int32_t pre
 }  // extern "C"
 
 #include "svb_frame.h"
+#include "svb_listframe.h"

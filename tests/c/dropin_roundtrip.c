@@ -47,6 +47,20 @@ int main(void) {
   if (svbframe_decode_many(frames, written, tmp, n, &nvalues) != SVBFRAME_OK || memcmp(in, tmp, n * 4)) return 13;
   frames[3] ^= 0x40; /* magic */
   if (svbframe_decode_many(frames, written, tmp, n, &nvalues) != SVBFRAME_EBADFRAME) return 14;
+  /* list frames: the same values as 1000 lists of growing length (the first one empty) */
+  enum { NLISTS = 1000 };
+  uint64_t start[NLISTS + 1], start_back[NLISTS + 1];
+  for (uint32_t i = 0; i <= NLISTS; i++) start[i] = (uint64_t)n * i / NLISTS * i / NLISTS;
+  size_t lcap = svbframe_lists_max_bytes(n, NLISTS, 30000), nlists = 0;
+  uint8_t *lframes = malloc(lcap);
+  if (svbframe_encode_lists(in, start, NLISTS, 30000, SVBGPU_0124, 0, lframes, lcap, &written) != SVBFRAME_OK) return 15;
+  if (svbframe_decode_lists(lframes, written, NULL, 0, NULL, 0, &nlists, &nvalues) != SVBFRAME_OK || nlists != NLISTS ||
+      nvalues != n)
+    return 16;
+  memset(tmp, 0, n * 4);
+  if (svbframe_decode_lists(lframes, written, tmp, n, start_back, NLISTS, &nlists, &nvalues) != SVBFRAME_OK ||
+      memcmp(in, tmp, n * 4) || memcmp(start, start_back, sizeof(start)))
+    return 17;
   printf("drop-in round trips ok (%zu bytes)\n", a);
   return 0;
 }

@@ -59,3 +59,35 @@ for p in (pi, pf, po):
 frames = np.empty(cap, dtype=np.uint8)
 out = np.empty(n, dtype=np.uint32)
 run("pageable", v.ctypes.data, frames.ctypes.data, out.ctypes.data)
+
+# list frames: posting lists of log-uniform length 1..4096, sorted, delta coded, whole lists per frame
+n_lists = max(1, n // 492)
+lens = np.floor(np.exp(rng.uniform(0, np.log(4096), n_lists))).astype(np.int64)
+start = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+nl_values = int(start[-1])
+gaps = (rng.integers(1, 1 << 16, size=nl_values, dtype=np.uint32) >> rng.integers(0, 12, size=nl_values, dtype=np.uint32)) + 1
+lists = np.cumsum(gaps, dtype=np.uint64).astype(np.uint32)
+lists -= np.repeat(lists[start[:-1].astype(np.int64)] - gaps[start[:-1].astype(np.int64)], lens)  # every list starts near zero
+del gaps
+lcap = lib.svbframe_lists_max_bytes(nl_values, n_lists, fv)
+pi, pf, po = pinned(4 * nl_values), pinned(lcap), pinned(4 * nl_values)
+C.memmove(pi, lists.ctypes.data, 4 * nl_values)
+start_back = np.empty(n_lists + 1, dtype=np.uint64)
+written, nl, nv = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+best_e = best_d = 1e9
+for _ in range(4):
+    t0 = time.perf_counter()
+    rc = lib.svbframe_encode_lists(pi, start.ctypes.data, n_lists, fv, 0, 1, pf, lcap, C.addressof(written))
+    t1 = time.perf_counter()
+    assert rc == 0, rc
+    rc = lib.svbframe_decode_lists(pf, written.value, po, nl_values, start_back.ctypes.data, n_lists, C.addressof(nl),
+                                   C.addressof(nv))
+    t2 = time.perf_counter()
+    assert rc == 0 and nv.value == nl_values and nl.value == n_lists, (rc, nv.value, nl.value)
+    best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
+back = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(nl_values,))
+assert np.array_equal(back, lists) and np.array_equal(start_back, start)
+print(f"pinned    list frames, {n_lists} delta-coded lists, {nl_values} values: encode {4 * nl_values / best_e / 1e9:6.1f} GB/s, "
+      f"decode {4 * nl_values / best_d / 1e9:6.1f} GB/s (uint32 side); {written.value / nl_values:.2f} frame bytes per value")
+for p in (pi, pf, po):
+    lib.svbframe_free_pinned(p)
