@@ -146,6 +146,24 @@ int svbgpu_zigzag_delta_decode(const uint32_t *d_in, int32_t *d_out, size_t n, i
                                void *d_workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Differential decode fused with an intersection.  The stream at d_in holds
+ * `count` values coded as streamvbyte_delta_encode / svbgpu_encode with
+ * SVBGPU_DELTA writes them (reference include/streamvbytedelta.h:19,29);
+ * d_sorted[0 .. n_sorted) is ascending.  d_out receives, in stream order,
+ * every decoded value that occurs in d_sorted (needs room for `count` values:
+ * a stream may repeat a value), *d_n_out their number, *d_consumed (optional)
+ * the stream's bytes.  The decoded array itself is never written.  No
+ * counterpart in the reference, whose callers decode and then intersect.
+ * Meant for ascending streams (posting lists); any stream gives the right
+ * answer, but one whose values jump about makes every wavefront walk much of
+ * d_sorted.  Workspace as for svbgpu_decode.
+ */
+int svbgpu_decode_intersect(int variant, const uint8_t *d_in, uint32_t count, uint32_t prev,
+                            const uint32_t *d_sorted, uint32_t n_sorted, uint32_t *d_out,
+                            uint64_t *d_n_out, void *d_workspace, size_t workspace_bytes,
+                            uint64_t *d_consumed, void *stream);
+
+/*
  * Batched entry points: `nstreams` independent streams in one launch (posting
  * lists, gradient chunks).  No counterpart in the reference, whose callers loop
  * over streamvbyte_encode/decode one stream at a time (e.g. reference

@@ -303,6 +303,21 @@ class DeviceCodec:
                                                      self._res_ptr(1), self._stream()), "svbgpu_decode_dequantize")
         return out, self.res[1:2]
 
+    def decode_intersect(self, stream, count, sorted_values, out=None, variant=V1234, prev=0):
+        """delta-coded stream x ascending uint32/int32-bits tensor -> (matches buffer, n_matches_tensor[1],
+        consumed_tensor[1]); the first n_matches entries of the buffer are the stream's values found in
+        sorted_values, in stream order."""
+        torch = self.torch
+        assert count <= self.max_count and stream.is_contiguous() and sorted_values.is_contiguous()
+        if out is None:
+            out = torch.empty(max(count, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode_intersect(variant, stream.data_ptr(), count, prev & 0xFFFFFFFF,
+                                                    sorted_values.data_ptr(), sorted_values.numel(), out.data_ptr(),
+                                                    self._res_ptr(4), self.ws.data_ptr(), self.ws_bytes,
+                                                    self._res_ptr(1), self._stream()), "svbgpu_decode_intersect")
+        return out, self.res[4:5], self.res[1:2]
+
     def decode_plan(self, stream, count, variant=V1234):
         with self.torch.cuda.device(self.device):
             _check(self.lib.svbgpu_decode_plan(variant, stream.data_ptr(), count, self.ws.data_ptr(),

@@ -22,6 +22,7 @@
 #include "svb_misc.h"
 #include "svb_batch.h"
 #include "svb_lists.h"
+#include "svb_intersect.h"
 
 using namespace svb;
 
@@ -490,6 +491,52 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   hipLaunchKernelGGL(k_running_sum<true>, dim3(stream_grid(L.n_tiles, 4)), dim3(kBlock), 0, S(stream), d_in,
                      reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, (u32)L.n_tiles, ws_hdr(ws),
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+extern "C++" {
+template <int V>
+void launch_intersect(const uint8_t* d_in, uint32_t count, uint32_t prev, const uint32_t* d_sorted,
+                      uint32_t n_sorted, uint32_t* d_out, uint64_t* d_n_out, void* ws, uint64_t* d_consumed,
+                      hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, 7);
+  u64* super_off = ws_at<u64>(ws, L.off_super_off);
+  u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
+  u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
+  u32* blk = ws_at<u32>(ws, L.off_blk);
+  const unsigned nblk = (unsigned)((L.n_wt + 1023) / 1024);
+  hipLaunchKernelGGL((k_value_sums<V, false>), dim3(grid), dim3(kBlock), 0, st, d_in, count, super_off, wt_rel, vsum);
+  hipLaunchKernelGGL(k_scan_u32_blocks, dim3(nblk), dim3(kBlock), 0, st, vsum, (u32)L.n_wt, blk);
+  hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, st, blk, nblk, prev);
+  hipLaunchKernelGGL((k_delta_intersect<V>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count, super_off,
+                     wt_rel, vsum, blk, d_sorted, n_sorted, d_out, d_n_out, (u32)L.n_tiles, ws_hdr(ws),
+                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+}
+}  // extern "C++"
+
+int svbgpu_decode_intersect(int variant, const uint8_t* d_in, uint32_t count, uint32_t prev,
+                            const uint32_t* d_sorted, uint32_t n_sorted, uint32_t* d_out, uint64_t* d_n_out,
+                            void* ws, size_t ws_bytes, uint64_t* d_consumed, void* stream) {
+  if (bad_variant(variant) || !d_n_out || (n_sorted && !d_sorted)) return SVBGPU_EINVAL;
+  if (count == 0) {
+    int rc0 = fill_u32(d_n_out, 0u, 8, S(stream));
+    if (!rc0 && d_consumed) rc0 = fill_u32(d_consumed, 0u, 8, S(stream));
+    return rc0;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = clear_lookback(count, ws, S(stream));
+  if (rc) return rc;
+  rc = build_directory(variant, d_in, count, ws, S(stream));
+  if (rc) return rc;
+  if (variant == SVBGPU_1234)
+    launch_intersect<V1234>(d_in, count, prev, d_sorted, n_sorted, d_out, d_n_out, ws, d_consumed, S(stream));
+  else
+    launch_intersect<V0124>(d_in, count, prev, d_sorted, n_sorted, d_out, d_n_out, ws, d_consumed, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

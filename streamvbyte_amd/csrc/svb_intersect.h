@@ -1,0 +1,224 @@
+// Differential decode fused with an intersection: the values of a delta-coded
+// stream that also occur in a sorted array, written in stream order, without the
+// decoded array ever reaching memory.
+//
+// The reference stops at the decoded array (streamvbyte_delta_decode,
+// src/streamvbytedelta_decode.c:63-74); intersecting posting lists is what its
+// users do with it next (README.md:30-39 there).
+//
+// Structure: the two-pass differential decoder's pre-pass gives every wave tile
+// the sum of all values before it (k_value_sums + scans, svb_delta.h).  One
+// workgroup then takes a tile of 16 wave tiles in ticket order; each wave decodes
+// its 4096 values into registers, finds the part of the sorted array that lies
+// between its smallest and largest value with two 64-way searches, walks that
+// part through LDS 1024 entries at a time and looks every value up by binary
+// search in LDS.  The number of hits travels through the decoupled look-back,
+// which gives every tile its place in the output.
+#pragma once
+#include "svb_delta.h"
+
+namespace svb {
+
+// Maximum over the wavefront, wave-uniform (the DPP pattern of wave_scan_incl;
+// the zero shifted in is the identity of max on unsigned values).
+__device__ __forceinline__ u32 wave_max(u32 x) {
+  x = max(x, dpp_zero<0x111, 0xF>(x));
+  x = max(x, dpp_zero<0x112, 0xF>(x));
+  x = max(x, dpp_zero<0x114, 0xF>(x));
+  x = max(x, dpp_zero<0x118, 0xF>(x));
+  x = max(x, dpp_zero<0x142, 0xA>(x));
+  x = max(x, dpp_zero<0x143, 0xC>(x));
+  return wave_last(x);
+}
+
+// First index i of the ascending array b[0..n) with b[i] >= key (GT false) or
+// b[i] > key (GT true), n if there is none.  key and the result are
+// wave-uniform; every step probes 64 places, so 2^32 entries take six steps.
+template <bool GT>
+__device__ __forceinline__ u32 wave_bound(const u32* __restrict__ b, u32 n, u32 key, int lane) {
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 step = (hi - lo + 63u) >> 6;
+    const u64 idx = (u64)lo + (u64)lane * step;
+    bool ok = true;  // places past hi count as "large enough"
+    if (idx < hi) {
+      const u32 x = b[idx];
+      ok = GT ? x > key : x >= key;
+    }
+    const u64 m = __ballot(ok);
+    const u32 first = m ? (u32)__builtin_ctzll(m) : 64u;  // the probes before it fail, it and all after it pass
+    if (first == 0) {
+      hi = lo;
+    } else {
+      const u64 nh = (u64)lo + (u64)first * step;
+      lo = lo + (first - 1) * step + 1;
+      hi = (u32)min((u64)hi, nh);
+    }
+  }
+  return lo;
+}
+
+// Which of the four values of c (those flagged in `valid`) occur in the sorted
+// LDS array buf[0..len), len <= 1024, entries from len to 1023 hold 0xFFFFFFFF?
+// first / last = buf[0] / buf[len-1].  Returns a 4-bit mask.
+__device__ __forceinline__ u32 lds_find4(const u32* buf, u32 len, u32 first, u32 last, const uint4& c, u32 valid) {
+  const bool r0 = (valid & 1u) && c.x >= first && c.x <= last;
+  const bool r1 = (valid & 2u) && c.y >= first && c.y <= last;
+  const bool r2 = (valid & 4u) && c.z >= first && c.z <= last;
+  const bool r3 = (valid & 8u) && c.w >= first && c.w <= last;
+  if (__ballot(r0 || r1 || r2 || r3) == 0ull) return 0u;
+  u32 p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+  for (u32 step = 512; step; step >>= 1) {  // four independent lower-bound searches
+    const u32 a0 = buf[p0 + step - 1], a1 = buf[p1 + step - 1], a2 = buf[p2 + step - 1], a3 = buf[p3 + step - 1];
+    p0 += a0 < c.x ? step : 0u;
+    p1 += a1 < c.y ? step : 0u;
+    p2 += a2 < c.z ? step : 0u;
+    p3 += a3 < c.w ? step : 0u;
+  }
+  u32 m = 0;
+  m |= (r0 && p0 < len && buf[p0] == c.x) ? 1u : 0u;
+  m |= (r1 && p1 < len && buf[p1] == c.y) ? 2u : 0u;
+  m |= (r2 && p2 < len && buf[p2] == c.z) ? 4u : 0u;
+  m |= (r3 && p3 < len && buf[p3] == c.w) ? 8u : 0u;
+  return m;
+}
+
+// out[0 .. *n_out) = the values a_i of the stream (a_i = prev + d_0 + ... + d_i,
+// wrap-around) with a_i in b[0..n_b), in stream order.  b ascending.  wt_vpre +
+// blk_pre: sum of everything before a wave tile, prev included (made by
+// k_value_sums, k_scan_u32_blocks, k_scan_u32_top).  One workgroup per tile of
+// 16 wave tiles, header and look-back words zero before the launch.
+// Meant for ascending streams (posting lists): a wave whose values are not
+// ascending still gets the right answer but may walk much of b.
+template <int V>
+__global__ __launch_bounds__(kBlock, 3) void k_delta_intersect(
+    const u8* __restrict__ in, u32 count, const u64* __restrict__ super_off,
+    const u32* __restrict__ wt_rel, const u32* __restrict__ wt_vpre, const u32* __restrict__ blk_pre,
+    const u32* __restrict__ b, u32 n_b, u32* __restrict__ out, u64* __restrict__ n_out, u32 n_tiles,
+    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
+  __shared__ WaveLds s_lds[kWaves];
+  __shared__ u32 s_wave_tot[kWaves];
+  __shared__ u64 s_prefix;
+  __shared__ u32 s_tile;
+  const int lane = lane_id(), wave = wave_id();
+  if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+  __syncthreads();
+  const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
+  WaveLds& S = s_lds[wave];
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u8* data_base = in + keylen;
+  const u32 wt0 = tile * kLbWt + wave * 4;
+
+  // ---- decode the wave's 4 wave tiles and turn them into values ----
+  uint4 v[4][4];
+  u32 nints[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32 wt = wt0 + q;
+    nints[q] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
+    if (wt < n_wt) {
+      const u64 koff = (u64)wt * kWtKeys + 4 * lane;
+      const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
+      const u64 doff = super_off[wt / kSuperWt] + wt_rel[wt];
+      const u64 int0 = (u64)wt * kWtInts;
+      nints[q] = (u32)min((u64)kWtInts, (u64)count - int0);
+      const u32 total = decode_wavetile<V, false>(w, nints[q], data_base + doff, lane, S, v[q]);
+      if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;
+      u32 run = wt_vpre[wt] + blk_pre[wt >> 10];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4& c = v[q][j];
+        c.y += c.x; c.z += c.y; c.w += c.z;
+        const u32 incl = wave_scan_incl(c.w, lane);
+        const u32 ex = incl - c.w + run;
+        run += wave_last(incl);
+        c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+      }
+    }
+  }
+
+  // ---- the span of the wave's values, and the part of b inside it ----
+  u32 vmax = 0, vmin_inv = 0;  // min as the max of the complements
+  u32 valid[4][4];             // 4-bit masks of the values that exist
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 first = 4u * (j * 64 + lane);
+      const u32 left = nints[q] > first ? nints[q] - first : 0u;
+      const u32 m = left >= 4u ? 15u : ((1u << left) - 1u);
+      valid[q][j] = m;
+      const uint4& c = v[q][j];
+      if (m & 1u) { vmax = max(vmax, c.x); vmin_inv = max(vmin_inv, ~c.x); }
+      if (m & 2u) { vmax = max(vmax, c.y); vmin_inv = max(vmin_inv, ~c.y); }
+      if (m & 4u) { vmax = max(vmax, c.z); vmin_inv = max(vmin_inv, ~c.z); }
+      if (m & 8u) { vmax = max(vmax, c.w); vmin_inv = max(vmin_inv, ~c.w); }
+    }
+  vmax = wave_max(vmax);
+  const u32 vmin = ~wave_max(vmin_inv);
+  u32 lo = 0, hi = 0;
+  if (nints[0] && n_b) {  // the wave has values (its first wave tile does) and b has entries
+    lo = wave_bound<false>(b, n_b, vmin, lane);
+    hi = wave_bound<true>(b, n_b, vmax, lane);
+  }
+
+  // ---- walk b[lo, hi) through LDS, look every value up ----
+  u32* buf = reinterpret_cast<u32*>(S.data);
+  static_assert(sizeof(S.data) >= 4096, "the wave's LDS image holds 1024 entries of the sorted array");
+  u64 hits = 0;  // bit q*16 + j*4 + k
+  for (u64 pos = lo; pos < hi; pos += 1024) {
+    const u32 len = (u32)min((u64)1024, (u64)hi - pos);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const u32 e = i * 64 + lane;
+      buf[e] = e < len ? b[pos + e] : 0xFFFFFFFFu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 first = buf[0], last = buf[len - 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hits |= (u64)lds_find4(buf, len, first, last, v[q][j], valid[q][j]) << (q * 16 + j * 4);
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- the tile's place in the output ----
+  const u32 wave_tot = wave_sum((u32)__popcll(hits));
+  if (lane == 0) s_wave_tot[wave] = wave_tot;
+  __syncthreads();
+  if (wave == 0) {
+    const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    const u64 excl = lb2_exclusive_prefix<1>(lb, tile, tile_tot, lane, &hdr->error);
+    if (lane == 0) {
+      s_prefix = excl;
+      if (tile == n_tiles - 1) *n_out = excl + tile_tot;
+    }
+  }
+  __syncthreads();
+  u64 base = s_prefix;
+  for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+  if (wave_tot == 0) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 m = (u32)(hits >> (q * 16 + j * 4)) & 15u;
+      const u32 c = (u32)__popc(m);
+      const u32 incl = wave_scan_incl(c, lane);
+      u32* p = out + base + (incl - c);
+      base += wave_last(incl);
+      const uint4& r = v[q][j];
+      if (m & 1u) *p++ = r.x;
+      if (m & 2u) *p++ = r.y;
+      if (m & 4u) *p++ = r.z;
+      if (m & 8u) *p++ = r.w;
+    }
+}
+
+}  // namespace svb

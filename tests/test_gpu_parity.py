@@ -439,3 +439,42 @@ def test_quantized_floats_fused(torch_mod, codec, oracle, variant):
         acc = torch.from_numpy(acc0.copy()).cuda()
         codec.decode_dequantize(dev_stream(torch, expect), n, float(step), out=acc, accumulate=True, variant=variant)
         assert np.array_equal(acc.cpu().numpy(), acc0 + want), (n,)
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+def test_decode_intersect(torch_mod, codec, oracle, variant):
+    """Differential decode fused with an intersection = decode (oracle) then numpy isin,
+    for sparse, similar and dense sorted arrays, repeats, extremes and streams that wrap."""
+    torch = torch_mod
+    rng = np.random.default_rng(90 + variant)
+    cases = []
+    for n in (1, 3, 1023, 1025, 4096, 4097, 16384, 16385, 65537, 300001, 1 << 20):
+        gaps = rng.integers(0, 40, n, dtype=np.uint64)          # ascending, with repeats (gap 0)
+        cases.append((np.cumsum(gaps).astype(np.uint32), 0))
+    wide = np.cumsum(rng.integers(1, 3000, 200000, dtype=np.uint64)).astype(np.uint32)
+    cases.append((wide, 0))
+    cases.append(((np.cumsum(rng.integers(0, 40, 70000, dtype=np.uint64)) + 0xFFFF0000).astype(np.uint32), 0))  # wraps
+    cases.append((GENERATORS["width_mix"](rng, 20000), 5))       # values that jump about
+    for v, prev in cases:
+        n = v.size
+        s = oracle.encode(variant, v, True, prev)
+        top = int(v.max()) + 50
+        sets = [rng.integers(0, top, max(1, n // 50), dtype=np.uint64),       # much sparser than the stream
+                rng.integers(0, top, n, dtype=np.uint64),                     # about as dense
+                rng.integers(0, top, min(20 * n, 1 << 21), dtype=np.uint64),  # much denser
+                np.array([0, 0xFFFFFFFF], dtype=np.uint64),
+                np.zeros(0, dtype=np.uint64),
+                v[:: 3].astype(np.uint64)]                                     # every third value certainly hits
+        for b in sets:
+            b = np.unique(b.astype(np.uint32))
+            expect = v[np.isin(v, b)]
+            d_b = to_dev(torch, b) if b.size else torch.empty(0, dtype=torch.int32, device="cuda:0")
+            out, n_out, used = codec.decode_intersect(dev_stream(torch, s), n, d_b, variant=variant, prev=prev)
+            codec.check()
+            assert int(used.item()) == s.size
+            assert int(n_out.item()) == expect.size, (n, b.size)
+            assert np.array_equal(to_np(out[: expect.size], np.uint32), expect), (n, b.size)
+    # empty stream
+    out, n_out, used = codec.decode_intersect(dev_stream(torch, np.zeros(0, dtype=np.uint8)), 0, to_dev(torch, wide),
+                                              variant=variant)
+    assert int(n_out.item()) == 0 and int(used.item()) == 0
