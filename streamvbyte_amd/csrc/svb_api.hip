@@ -510,8 +510,13 @@ void launch_intersect(const uint8_t* d_in, uint32_t count, uint32_t prev, const 
   hipLaunchKernelGGL((k_value_sums<V, false>), dim3(grid), dim3(kBlock), 0, st, d_in, count, super_off, wt_rel, vsum);
   hipLaunchKernelGGL(k_scan_u32_blocks, dim3(nblk), dim3(kBlock), 0, st, vsum, (u32)L.n_wt, blk);
   hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, st, blk, nblk, prev);
+  u32* bound = ws_at<u32>(ws, L.off_bounds);
+  const u32 n_waves = (u32)((L.n_wt + 3) / 4);
+  if (n_sorted)
+    hipLaunchKernelGGL(k_wave_bounds, dim3((n_waves + kBlock - 1) / kBlock), dim3(kBlock), 0, st, vsum, blk, n_waves,
+                       d_sorted, n_sorted, bound);
   hipLaunchKernelGGL((k_delta_intersect<V>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count, super_off,
-                     wt_rel, vsum, blk, d_sorted, n_sorted, d_out, d_n_out, (u32)L.n_tiles, ws_hdr(ws),
+                     wt_rel, vsum, blk, d_sorted, n_sorted, bound, d_out, d_n_out, (u32)L.n_tiles, ws_hdr(ws),
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
 }
 }  // extern "C++"

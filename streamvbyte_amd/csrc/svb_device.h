@@ -183,7 +183,7 @@ static_assert(sizeof(WsHeader) == 256, "header is one 256-byte block");
 
 struct WsLayout {
   u64 n_wt, n_super, n_tiles;
-  size_t off_super_off, off_wt_rel, off_super_sum, off_status, off_lb_group, off_wt_vsum, off_blk, total;
+  size_t off_super_off, off_wt_rel, off_super_sum, off_status, off_lb_group, off_wt_vsum, off_blk, off_bounds, total;
 };
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kLbWt = 16;  // wave tiles per look-back tile (16384 values)
@@ -203,6 +203,7 @@ __host__ __device__ inline WsLayout ws_layout(u32 count) {
   L.off_super_sum = o; o += align256(4 * L.n_super);
   L.off_wt_vsum = o;   o += align256(4 * L.n_wt);            // per-wave-tile value sums (delta decode)
   L.off_blk = o;       o += align256(4 * (L.n_wt / 1024 + 2));
+  L.off_bounds = o;    o += align256(4 * (L.n_wt / 4 + 2));  // one place in the sorted array per 4 wave tiles (intersection)
   L.total = o;
   return L;
 }

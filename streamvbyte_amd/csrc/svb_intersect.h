@@ -58,18 +58,40 @@ __device__ __forceinline__ u32 wave_bound(const u32* __restrict__ b, u32 n, u32 
   return lo;
 }
 
+// bound[w] = first index i with b[i] >= the value that precedes wave w's first
+// (wave w takes wave tiles 4w..4w+3; wt_vpre + blk_pre as in k_delta_intersect).
+// Of an ascending stream every value of wave w lies between the values that
+// precede waves w and w+1, so b[bound[w] .. bound[w+1]] is all it can meet.
+// One thread per wave; neighbouring threads search for neighbouring keys.
+__global__ __launch_bounds__(kBlock) void k_wave_bounds(const u32* __restrict__ wt_vpre,
+                                                        const u32* __restrict__ blk_pre, u32 n_waves,
+                                                        const u32* __restrict__ b, u32 n_b,
+                                                        u32* __restrict__ bound) {
+  const u32 w = blockIdx.x * kBlock + threadIdx.x;
+  if (w >= n_waves) return;
+  const u32 key = wt_vpre[4 * w] + blk_pre[(4 * w) >> 10];
+  u32 lo = 0, hi = n_b;
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (b[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  bound[w] = lo;
+}
+
 // Which of the four values of c (those flagged in `valid`) occur in the sorted
 // LDS array buf[0..len), len <= 1024, entries from len to 1023 hold 0xFFFFFFFF?
-// first / last = buf[0] / buf[len-1].  Returns a 4-bit mask.
-__device__ __forceinline__ u32 lds_find4(const u32* buf, u32 len, u32 first, u32 last, const uint4& c, u32 valid) {
+// first / last = buf[0] / buf[len-1]; top = half the smallest power of two >= len
+// (wave-uniform: the searches only look at the first 2*top entries).  Returns a
+// 4-bit mask.
+__device__ __forceinline__ u32 lds_find4(const u32* buf, u32 len, u32 top, u32 first, u32 last, const uint4& c,
+                                         u32 valid) {
   const bool r0 = (valid & 1u) && c.x >= first && c.x <= last;
   const bool r1 = (valid & 2u) && c.y >= first && c.y <= last;
   const bool r2 = (valid & 4u) && c.z >= first && c.z <= last;
   const bool r3 = (valid & 8u) && c.w >= first && c.w <= last;
   if (__ballot(r0 || r1 || r2 || r3) == 0ull) return 0u;
   u32 p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll
-  for (u32 step = 512; step; step >>= 1) {  // four independent lower-bound searches
+  for (u32 step = top; step; step >>= 1) {  // four independent lower-bound searches
     const u32 a0 = buf[p0 + step - 1], a1 = buf[p1 + step - 1], a2 = buf[p2 + step - 1], a3 = buf[p3 + step - 1];
     p0 += a0 < c.x ? step : 0u;
     p1 += a1 < c.y ? step : 0u;
@@ -84,6 +106,32 @@ __device__ __forceinline__ u32 lds_find4(const u32* buf, u32 len, u32 first, u32
   return m;
 }
 
+// The same question answered from a bitmap: bit x - first of bits[] is set for
+// every entry x of the sorted array between first and last.
+__device__ __forceinline__ u32 lds_bits4(const u32* bits, u32 first, u32 last, const uint4& c, u32 valid) {
+  const bool r0 = (valid & 1u) && c.x >= first && c.x <= last;
+  const bool r1 = (valid & 2u) && c.y >= first && c.y <= last;
+  const bool r2 = (valid & 4u) && c.z >= first && c.z <= last;
+  const bool r3 = (valid & 8u) && c.w >= first && c.w <= last;
+  if (__ballot(r0 || r1 || r2 || r3) == 0ull) return 0u;
+  const u32 d0 = r0 ? c.x - first : 0u, d1 = r1 ? c.y - first : 0u, d2 = r2 ? c.z - first : 0u,
+            d3 = r3 ? c.w - first : 0u;
+  const u32 w0 = bits[d0 >> 5], w1 = bits[d1 >> 5], w2 = bits[d2 >> 5], w3 = bits[d3 >> 5];
+  u32 m = 0;
+  m |= (r0 && ((w0 >> (d0 & 31u)) & 1u)) ? 1u : 0u;
+  m |= (r1 && ((w1 >> (d1 & 31u)) & 1u)) ? 2u : 0u;
+  m |= (r2 && ((w2 >> (d2 & 31u)) & 1u)) ? 4u : 0u;
+  m |= (r3 && ((w3 >> (d3 & 31u)) & 1u)) ? 8u : 0u;
+  return m;
+}
+
+// 4-bit mask of the values of group j*64+lane that exist in a wave tile of nints values.
+__device__ __forceinline__ u32 valid4(u32 nints, int j, int lane) {
+  const u32 first = 4u * (j * 64 + lane);
+  const u32 left = nints > first ? nints - first : 0u;
+  return left >= 4u ? 15u : ((1u << left) - 1u);
+}
+
 // out[0 .. *n_out) = the values a_i of the stream (a_i = prev + d_0 + ... + d_i,
 // wrap-around) with a_i in b[0..n_b), in stream order.  b ascending.  wt_vpre +
 // blk_pre: sum of everything before a wave tile, prev included (made by
@@ -92,11 +140,11 @@ __device__ __forceinline__ u32 lds_find4(const u32* buf, u32 len, u32 first, u32
 // Meant for ascending streams (posting lists): a wave whose values are not
 // ascending still gets the right answer but may walk much of b.
 template <int V>
-__global__ __launch_bounds__(kBlock, 3) void k_delta_intersect(
+__global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
     const u8* __restrict__ in, u32 count, const u64* __restrict__ super_off,
     const u32* __restrict__ wt_rel, const u32* __restrict__ wt_vpre, const u32* __restrict__ blk_pre,
-    const u32* __restrict__ b, u32 n_b, u32* __restrict__ out, u64* __restrict__ n_out, u32 n_tiles,
-    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
+    const u32* __restrict__ b, u32 n_b, const u32* __restrict__ bound, u32* __restrict__ out,
+    u64* __restrict__ n_out, u32 n_tiles, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
   __shared__ WaveLds s_lds[kWaves];
   __shared__ u32 s_wave_tot[kWaves];
   __shared__ u64 s_prefix;
@@ -114,21 +162,34 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_intersect(
   // ---- decode the wave's 4 wave tiles and turn them into values ----
   uint4 v[4][4];
   u32 nints[4];
+  // keys, data offsets and preceding sums of the wave's 4 wave tiles up front
+  u32 w[4], vpre[4];
+  u64 doff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32 wt = wt0 + q;
+    w[q] = 0;
+    doff[q] = 0;
+    vpre[q] = 0;
     nints[q] = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
     if (wt < n_wt) {
       const u64 koff = (u64)wt * kWtKeys + 4 * lane;
-      const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
-      const u64 doff = super_off[wt / kSuperWt] + wt_rel[wt];
-      const u64 int0 = (u64)wt * kWtInts;
-      nints[q] = (u32)min((u64)kWtInts, (u64)count - int0);
-      const u32 total = decode_wavetile<V, false>(w, nints[q], data_base + doff, lane, S, v[q]);
-      if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;
-      u32 run = wt_vpre[wt] + blk_pre[wt >> 10];
+      if (koff < keylen) w[q] = ld_u32(in + koff);
+      doff[q] = super_off[wt / kSuperWt] + wt_rel[wt];
+      vpre[q] = wt_vpre[wt] + blk_pre[wt >> 10];
+      nints[q] = (u32)min((u64)kWtInts, (u64)count - (u64)wt * kWtInts);
+    }
+  }
+  const u32 before = vpre[0];  // the value preceding the wave's first
+  u32 last_value = before;     // the wave's last value
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
+    if (nints[q]) {
+      const u32 total = decode_wavetile<V, false>(w[q], nints[q], data_base + doff[q], lane, S, v[q]);
+      if (wt0 + q == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + total;
+      u32 run = vpre[q];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint4& c = v[q][j];
@@ -138,20 +199,17 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_intersect(
         run += wave_last(incl);
         c.x += ex; c.y += ex; c.z += ex; c.w += ex;
       }
+      last_value = run;  // absent values are zero deltas
     }
   }
 
   // ---- the span of the wave's values, and the part of b inside it ----
   u32 vmax = 0, vmin_inv = 0;  // min as the max of the complements
-  u32 valid[4][4];             // 4-bit masks of the values that exist
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const u32 first = 4u * (j * 64 + lane);
-      const u32 left = nints[q] > first ? nints[q] - first : 0u;
-      const u32 m = left >= 4u ? 15u : ((1u << left) - 1u);
-      valid[q][j] = m;
+      const u32 m = valid4(nints[q], j, lane);
       const uint4& c = v[q][j];
       if (m & 1u) { vmax = max(vmax, c.x); vmin_inv = max(vmin_inv, ~c.x); }
       if (m & 2u) { vmax = max(vmax, c.y); vmin_inv = max(vmin_inv, ~c.y); }
@@ -162,30 +220,66 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_intersect(
   const u32 vmin = ~wave_max(vmin_inv);
   u32 lo = 0, hi = 0;
   if (nints[0] && n_b) {  // the wave has values (its first wave tile does) and b has entries
-    lo = wave_bound<false>(b, n_b, vmin, lane);
-    hi = wave_bound<true>(b, n_b, vmax, lane);
+    const u32 w = wt0 >> 2;
+    if (vmin >= before && vmax <= last_value && wt0 + 4 < n_wt) {
+      // ascending so far as it matters, and not the last wave: the pre-pass knows the places
+      lo = bound[w];
+      hi = min(n_b, bound[w + 1] + 1u);  // bound[w+1] is where last_value would be
+    } else {
+      lo = wave_bound<false>(b, n_b, vmin, lane);
+      hi = wave_bound<true>(b, n_b, vmax, lane);
+    }
   }
 
-  // ---- walk b[lo, hi) through LDS, look every value up ----
+  // ---- walk b[lo, hi) through LDS a chunk at a time, look every value up ----
+  // Entries that lie close together (last - first < 32768: the usual case when b
+  // is about as dense as the stream or denser) become a bitmap, one LDS read per
+  // value; otherwise the entries themselves go to LDS and are searched.
   u32* buf = reinterpret_cast<u32*>(S.data);
   static_assert(sizeof(S.data) >= 4096, "the wave's LDS image holds 1024 entries of the sorted array");
   u64 hits = 0;  // bit q*16 + j*4 + k
-  for (u64 pos = lo; pos < hi; pos += 1024) {
-    const u32 len = (u32)min((u64)1024, (u64)hi - pos);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const u32 e = i * 64 + lane;
-      buf[e] = e < len ? b[pos + e] : 0xFFFFFFFFu;
+  for (u64 pos = lo; pos < hi;) {
+    // up to 4096 entries at a time if they fit the bitmap, else 1024
+    u32 len = (u32)min((u64)4096, (u64)hi - pos);
+    const u32 first = b[pos];  // wave-uniform
+    u32 last = b[pos + len - 1];
+    if (last - first >= 32768u && len > 1024u) {
+      len = 1024u;
+      last = b[pos + len - 1];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const u32 first = buf[0], last = buf[len - 1];
+    if (last - first < 32768u) {
+      const u32 nw = ((last - first) >> 5) + 1u;
+      for (u32 e = lane; e < nw; e += 64) buf[e] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (u32 e = lane; e < len; e += 64) {
+        const u32 d = b[pos + e] - first;
+        atomicOr(&buf[d >> 5], 1u << (d & 31u));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        hits |= (u64)lds_find4(buf, len, first, last, v[q][j], valid[q][j]) << (q * 16 + j * 4);
+        for (int j = 0; j < 4; ++j)
+          hits |= (u64)lds_bits4(buf, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const u32 e = i * 64 + lane;
+        buf[e] = e < len ? b[pos + e] : 0xFFFFFFFFu;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const u32 top = len > 1u ? 1u << (31 - __builtin_clz(len - 1u)) : 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          hits |= (u64)lds_find4(buf, len, top, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
+    }
     __builtin_amdgcn_wave_barrier();
+    pos += len;
   }
 
   // ---- the tile's place in the output ----
