@@ -335,7 +335,21 @@ def main():
                                    "decode_GBps": round(4.0 * n3 / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n3 / ms_e / 1e6, 1),
                                    "decode_roofline_frac": round((4.25 + d3) * n3 / ms_d / 1e6 / HBM_PEAK_GBS, 4),
                                    "encode_roofline_frac": round((4.25 + d3) * n3 / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
-        del post, s3
+        # the same postings intersected with a sorted array (every 8th value of theirs) while they are decoded
+        pu = post.to(torch.int64) & 0xFFFFFFFF
+        sorted_b = torch.unique(pu[::8])
+        expect_hits = post[torch.isin(pu, sorted_b)]
+        sorted_b = torch.where(sorted_b >= (1 << 31), sorted_b - (1 << 32), sorted_b).to(torch.int32)
+        del pu
+        ms_i, _ = event_ms(torch, lambda: codec.decode_intersect(s3, n3, sorted_b, out=out, variant=svb.V1234), it)
+        _, n_hits, _ = codec.decode_intersect(s3, n3, sorted_b, out=out, variant=svb.V1234)
+        codec.check()
+        k_hits = int(n_hits.item())
+        extra["delta_postings"]["intersect"] = {
+            "sorted_entries": int(sorted_b.numel()), "hits": k_hits, "ms": round(ms_i, 4),
+            "Gvalues_per_s": round(n3 / ms_i / 1e6, 1),
+            "parity": bool(k_hits == expect_hits.numel() and torch.equal(out[:k_hits], expect_hits))}
+        del post, s3, sorted_b, expect_hits
         # C3 mixed: 1-3 byte gaps, running sum wraps modulo 2^32, prev != 0
         n3b = min(n, 1 << 26)
         r31 = torch.randint(0, 1 << 31, (n3b,), generator=g, device=device, dtype=torch.int64)
