@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity: sizes, value distributions, variants, flags, misalignments,
-single stream, batched and host-pointer calls.  python tools/fuzz_gpu.py [seconds] [seed]"""
+single stream, batched, host-pointer calls, frames and list frames (also corrupted), fused intersection.  python tools/fuzz_gpu.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -102,6 +102,36 @@ while time.time() < t_end:
         assert np.array_equal(used.cpu().numpy(), hs), ("batch used",) + tag
         if vals.size:
             assert np.array_equal(to_np(back, np.uint32), vals), ("batch decode",) + tag
+    if it % 9 == 0:  # list frames: round trip, then a corrupted copy must be refused or decode to something, never crash
+        ns = int(rng.integers(1, 600))
+        counts = rng.integers(0, int(rng.choice([8, 300, 5000])), size=ns)
+        start = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+        vals = blocky(int(start[-1])) if start[-1] else np.zeros(0, dtype=np.uint32)
+        fv = int(rng.integers(1, 200000))
+        fr = svb.frame_encode_lists(vals, start, fv, variant=variant, flags=flags)
+        got, got_start = svb.frame_decode_lists(fr)
+        assert np.array_equal(got, vals) and np.array_equal(got_start, start), ("list frames", ns, fv) + tag
+        bad = fr.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            where = int(rng.integers(0, min(bad.size, 4096))) if rng.random() < 0.7 else int(rng.integers(0, bad.size))
+            bad[where] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        try:
+            svb.frame_decode_lists(bad[: int(rng.integers(1, bad.size + 1))] if rng.random() < 0.3 else bad)
+        except svb.SvbError:
+            pass
+    if it % 6 == 0:  # differential decode fused with an intersection
+        a = np.cumsum(rng.integers(0, int(rng.choice([2, 40, 5000])), n, dtype=np.uint64)).astype(np.uint32) if rng.random() < 0.8 else v
+        pv = int(rng.integers(0, 1 << 32)) if rng.random() < 0.3 else 0
+        a = (a + np.uint32(pv)).astype(np.uint32)
+        sa = oracle.encode(variant, a, True, pv)
+        m = int(rng.choice([1, max(1, n // 30), n, 8 * n]))
+        b = np.unique(np.concatenate([rng.integers(0, int(a.max()) + 2, m, dtype=np.uint64).astype(np.uint32),
+                                      a[:: int(rng.integers(1, 50))]]))
+        exp_hits = a[np.isin(a, b)]
+        o, k, u = codec.decode_intersect(dev_stream(torch, sa), n, to_dev(torch, b), variant=variant, prev=pv)
+        codec.check()
+        assert int(u.item()) == sa.size and int(k.item()) == exp_hits.size, ("intersect count", m, pv) + tag
+        assert np.array_equal(to_np(o[: exp_hits.size], np.uint32), exp_hits), ("intersect", m, pv) + tag
 codec.lib.svbgpu_set_option(b"encode_tile", 4)
 codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
 print(f"fuzz ok: {it} cases, seed {seed}")
