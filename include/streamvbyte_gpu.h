@@ -59,6 +59,10 @@ int svbgpu_device_ok(void);
  *                               from their data bytes; 0: one code path for all
  *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
  *                               streaming passes; 1: single pass with look-back
+ *   "batch_lists_per_wave" = k  batched calls: a launch gets a workgroup per 4k
+ *                               streams, handed out as earlier ones finish
+ *                               (default 8); 0: one grid that fills the device,
+ *                               streams strided over it
  *   "zigzag_piece" = n          values per device scan of the host-pointer
  *                               zigzag_delta_decode (default 2^31; longer arrays
  *                               go in pieces)

@@ -191,6 +191,17 @@ int run_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out
 }
 
 size_t g_ws_bytes_hint = 0;
+// Batched kernels: a wave takes about this many lists, so that a launch has many more workgroups than fit
+// the device and the hardware hands them out as earlier ones finish.  Lists differ in length by orders of
+// magnitude; lists strided over a grid that just fills the device left some waves with 1.3x the average
+// work.  0 = such a persistent grid.  See svbgpu_set_option.
+unsigned g_batch_lists_per_wave = 8;
+inline unsigned batch_grid(uint32_t nstreams) {
+  const unsigned long long blocks = ((unsigned long long)nstreams + kWaves - 1) / kWaves;
+  const unsigned fill = stream_grid(blocks, 8);
+  if (g_batch_lists_per_wave == 0) return fill;
+  return (unsigned)std::max<unsigned long long>(fill, (blocks + g_batch_lists_per_wave - 1) / g_batch_lists_per_wave);
+}
 unsigned g_debug = 0;  // timing-only ablations (wrong results!), see svbgpu_set_option
 int g_encode_qw = 4;  // wave tiles per wave in k_encode (1, 2 or 4); see svbgpu_set_option
 
@@ -280,6 +291,11 @@ int svbgpu_set_option(const char* name, int value) {
   }
   if (!std::strcmp(name, "delta_decode_lookback")) {
     g_delta_lookback = value != 0;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "batch_lists_per_wave")) {
+    if (value < 0) return SVBGPU_EINVAL;
+    g_batch_lists_per_wave = (unsigned)value;
     return SVBGPU_OK;
   }
   if (!std::strcmp(name, "encode_tile")) {
@@ -554,7 +570,7 @@ int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t* d_values,
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_values || !d_value_off || !d_bytes || !d_byte_off || !d_counts || !d_sizes) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = stream_grid(((unsigned long long)nstreams + kWaves - 1) / kWaves, 8);
+  const unsigned grid = batch_grid(nstreams);
   DISPATCH_VDZ(launch_encode_batch, variant, flags, grid, d_values, d_value_off, d_bytes, d_byte_off,
                d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
@@ -568,7 +584,7 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, con
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_bytes || !d_byte_off || !d_values || !d_value_off || !d_counts) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = stream_grid(((unsigned long long)nstreams + kWaves - 1) / kWaves, 8);
+  const unsigned grid = batch_grid(nstreams);
   DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, d_bytes, d_byte_off, d_values, d_value_off,
                d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
