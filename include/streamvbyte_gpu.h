@@ -59,6 +59,11 @@ int svbgpu_device_ok(void);
  *                               from their data bytes; 0: one code path for all
  *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
  *                               streaming passes; 1: single pass with look-back
+ *   "decode_grid_per_cu" = k    decoders: 0 (default) a workgroup per 4096
+ *                               values, handed out in order by the hardware;
+ *                               k > 0: a persistent grid of k workgroups per CU
+ *                               with the wave tiles strided over it (slower:
+ *                               kept for comparison)
  *   "batch_lists_per_wave" = k  batched calls: a launch gets a workgroup per 4k
  *                               streams, handed out as earlier ones finish
  *                               (default 8); 0: one grid that fills the device,
