@@ -241,7 +241,7 @@ void launch_encode(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_
 template <int V, bool D, bool Z>
 void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* d_bytes,
                  hipStream_t st) {
-  const unsigned grid = stream_grid(((unsigned long long)count / 4 + kBlock - 1) / kBlock / 4 + 1, 4);
+  const unsigned grid = stream_grid(((unsigned long long)count / 4 + kSizeChunk - 1) / kSizeChunk, 8);
   hipLaunchKernelGGL((k_size<V, D, Z>), dim3(grid), dim3(kBlock), 0, st, d_in, count, prev, d_bytes);
 }
 

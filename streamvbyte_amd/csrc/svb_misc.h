@@ -29,13 +29,16 @@ __device__ __forceinline__ u64 block_sum64(u64 x, u64* s_tmp) {
 // With DELTA the widths are those of in[i]-in[i-1]; ZZ zigzag-maps the value
 // (or the difference) first.
 // *result must be zero before the launch.  Reads 4 B per value.
+constexpr u64 kSizeChunk = 64 * kBlock;  // quads (of 4 values) per workgroup: 256 KiB of input per atomic
 template <int V, bool DELTA, bool ZZ>
 __global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32 count, u32 prev,
                                                  u64* __restrict__ result) {
   __shared__ u64 s_tmp[kWaves];
   const u64 nquads = (u64)count >> 2;
   u64 acc = 0;
-  for (u64 q = (u64)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (u64)gridDim.x * kBlock) {
+  // workgroup b takes the contiguous quads [b * kSizeChunk, (b + 1) * kSizeChunk) (grid-stride beyond that)
+  for (u64 c0 = (u64)blockIdx.x * kSizeChunk; c0 < nquads; c0 += (u64)gridDim.x * kSizeChunk)
+  for (u64 q = c0 + threadIdx.x; q < min(nquads, c0 + kSizeChunk); q += kBlock) {
     uint4 x;
     __builtin_memcpy(&x, in + 4 * q, 16);
     u32 v[4] = {x.x, x.y, x.z, x.w};
