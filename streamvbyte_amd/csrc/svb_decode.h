@@ -258,10 +258,13 @@ __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, cons
 }
 
 // ---------------------------------------------------------------------------
-// k_decode: persistent waves, each loops over wave tiles (stride = waves in the
-// grid) with the next tile's keys and offset prefetched.  No inter-workgroup
-// dependency: data offsets come from the directory built by k_key_sums /
-// k_scan_super.  HBM traffic per value: 0.25 (keys) + dbar (data) + 4 (out).
+// k_decode: every wave takes wave tile blockIdx.x * kWaves + wave; the launch
+// normally has a workgroup per 4 wave tiles (fastest: the workgroups in flight
+// cover one advancing stretch of the stream).  On a smaller grid a wave goes on
+// with a grid stride, the next tile's keys and offset prefetched.  No
+// inter-workgroup dependency: data offsets come from the directory built by
+// k_key_sums / k_scan_super.  HBM traffic per value: 0.25 (keys) + dbar (data)
+// + 4 (out).
 // OUT: 0 = the integers; 1 = float32 (int32)value * scale (dequantise fused into the
 // store); 2 = the same added to what out already holds (dequantise-accumulate).
 // scale travels as the bits of `aux`.
