@@ -196,6 +196,15 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t *d_bytes,
                         const uint32_t *d_counts, const uint32_t *d_prev, uint32_t nstreams,
                         uint64_t *d_sizes, void *stream);
 
+/* streamvbyte_validate_stream / _0124 (reference include/streamvbyte.h:75,79)
+ * for every stream of a batch: d_ok[s] = 1 when the first d_counts[s] codes of
+ * the stream at d_bytes + d_byte_off[s] promise exactly d_lengths[s] bytes of
+ * keys and data together, else 0 (an empty stream is valid only with length 0,
+ * as in the reference).  Reads nothing beyond a stream's key bytes. */
+int svbgpu_validate_batch(int variant, const uint8_t *d_bytes, const uint64_t *d_byte_off,
+                          const uint64_t *d_lengths, const uint32_t *d_counts, uint32_t nstreams,
+                          uint32_t *d_ok, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -391,6 +391,17 @@ class DeviceCodec:
                                                 sizes.data_ptr(), self._stream()), "svbgpu_decode_batch")
         return sizes
 
+    def validate_batch(self, byte_buf, byte_off, lengths, counts, variant=V1234):
+        """Per-stream streamvbyte_validate_stream: int32 tensor of 1 / 0."""
+        torch = self.torch
+        ns = counts.numel()
+        ok = torch.empty(ns, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_validate_batch(variant, byte_buf.data_ptr(), byte_off.data_ptr(), lengths.data_ptr(),
+                                                  counts.data_ptr(), ns, ok.data_ptr(), self._stream()),
+                   "svbgpu_validate_batch")
+        return ok
+
     def check(self):
         """Synchronise and raise if a device scan gave up (never expected)."""
         with self.torch.cuda.device(self.device):

@@ -50,6 +50,7 @@ SIGNATURES = {
     "svbgpu_encode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbgpu_decode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     # include/streamvbyte_frame.h
+    "svbgpu_validate_batch": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbframe_max_bytes": (C.c_size_t, [C.c_uint32]),
     "svbframe_max_bytes_many": (C.c_size_t, [C.c_size_t, C.c_uint32]),
     "svbframe_peek": (C.c_int, [vp, C.c_size_t, vp]),

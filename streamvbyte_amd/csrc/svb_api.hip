@@ -574,6 +574,24 @@ int svbgpu_decode_intersect(int variant, const uint8_t* d_in, uint32_t count, ui
   return SVBGPU_OK;
 }
 
+int svbgpu_validate_batch(int variant, const uint8_t* d_bytes, const uint64_t* d_byte_off,
+                          const uint64_t* d_lengths, const uint32_t* d_counts, uint32_t nstreams,
+                          uint32_t* d_ok, void* stream) {
+  if (bad_variant(variant)) return SVBGPU_EINVAL;
+  if (nstreams == 0) return SVBGPU_OK;
+  if (!d_bytes || !d_byte_off || !d_lengths || !d_counts || !d_ok) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = batch_grid(nstreams);
+  if (variant == SVBGPU_1234)
+    hipLaunchKernelGGL((k_validate_lists<V1234, u64, true>), dim3(grid), dim3(kBlock), 0, S(stream), d_bytes, d_byte_off,
+                       d_counts, d_lengths, nstreams, d_ok);
+  else
+    hipLaunchKernelGGL((k_validate_lists<V0124, u64, true>), dim3(grid), dim3(kBlock), 0, S(stream), d_bytes, d_byte_off,
+                       d_counts, d_lengths, nstreams, d_ok);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
 int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t* d_values,
                         const uint64_t* d_value_off, uint8_t* d_bytes, const uint64_t* d_byte_off,
                         const uint32_t* d_counts, const uint32_t* d_prev, uint32_t nstreams,

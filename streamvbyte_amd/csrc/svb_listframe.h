@@ -322,10 +322,10 @@ int svbframe_decode_lists(const uint8_t* frames, size_t bytes, uint32_t* values,
     r = fill_u32(d_ok, 1u, 4, c->stream);
     if (r) return r;
     if (f.h.variant == SVBGPU_1234)
-      hipLaunchKernelGGL(k_validate_lists<V1234>, dim3(list_grid(f.h.n_lists)), dim3(kBlock), 0, c->stream,
+      hipLaunchKernelGGL((k_validate_lists<V1234, u32, false>), dim3(list_grid(f.h.n_lists)), dim3(kBlock), 0, c->stream,
                          static_cast<const uint8_t*>(c->a), d.byte_off, d.counts, d.sizes32, f.h.n_lists, d_ok);
     else
-      hipLaunchKernelGGL(k_validate_lists<V0124>, dim3(list_grid(f.h.n_lists)), dim3(kBlock), 0, c->stream,
+      hipLaunchKernelGGL((k_validate_lists<V0124, u32, false>), dim3(list_grid(f.h.n_lists)), dim3(kBlock), 0, c->stream,
                          static_cast<const uint8_t*>(c->a), d.byte_off, d.counts, d.sizes32, f.h.n_lists, d_ok);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_res + 1, c->d_res + 1, 8, hipMemcpyDeviceToHost, c->stream));

@@ -12,11 +12,14 @@ namespace svb {
 // (src/streamvbyte_decode.c:113-135, src/streamvbyte_0124_decode.c:206-228),
 // list by list.  *ok must be 1 before the launch and is cleared by any list that
 // fails.  One wavefront per list; reads 0.25 B per value.
-template <int V>
+// With PER_LIST the verdicts go to ok[s] (1 or 0, nothing need be preset) and a
+// size below the key bytes counts as a failure instead of being excluded by the
+// caller.
+template <int V, class SizeT, bool PER_LIST>
 __global__ __launch_bounds__(kBlock) void k_validate_lists(const u8* __restrict__ bytes,
                                                            const u64* __restrict__ byte_off,
                                                            const u32* __restrict__ counts,
-                                                           const u32* __restrict__ sizes, u32 n_lists,
+                                                           const SizeT* __restrict__ sizes, u32 n_lists,
                                                            u32* __restrict__ ok) {
   const u32 lane = lane_id();
   const u32 nwaves = gridDim.x * kWaves;
@@ -24,7 +27,11 @@ __global__ __launch_bounds__(kBlock) void k_validate_lists(const u8* __restrict_
     const u32 count = counts[s];
     const u32 keylen = (count + 3u) >> 2;
     const u8* in = bytes + byte_off[s];
-    u32 acc = 0;
+    if (PER_LIST && (u64)sizes[s] < keylen) {  // not even the keys fit: do not read them
+      if (lane == 0) ok[s] = 0u;
+      continue;
+    }
+    u64 acc = 0;
     for (u32 koff = 4u * lane; koff < keylen; koff += 256u) {
       u32 w = 0;
       if (koff + 4u <= keylen) {
@@ -35,8 +42,13 @@ __global__ __launch_bounds__(kBlock) void k_validate_lists(const u8* __restrict_
       const u32 nv = min(16u, count - 4u * koff);
       acc += word_len<V>(mask_codes(w, nv), nv);
     }
-    acc = wave_sum(acc);
-    if (lane == 0 && (u64)acc + keylen != (u64)sizes[s]) *ok = 0u;
+    acc = wave_sum64(acc);
+    const bool good = acc + keylen == (u64)sizes[s];
+    if (PER_LIST) {
+      if (lane == 0) ok[s] = good ? 1u : 0u;
+    } else if (lane == 0 && !good) {
+      *ok = 0u;
+    }
   }
 }
 

@@ -478,3 +478,31 @@ def test_decode_intersect(torch_mod, codec, oracle, variant):
     out, n_out, used = codec.decode_intersect(dev_stream(torch, np.zeros(0, dtype=np.uint8)), 0, to_dev(torch, wide),
                                               variant=variant)
     assert int(n_out.item()) == 0 and int(used.item()) == 0
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
+def test_validate_batch(torch_mod, codec, oracle, variant):
+    """svbgpu_validate_batch = the oracle's validate_stream stream by stream, for right and wrong lengths,
+    empty streams, lengths below the key bytes and tampered keys."""
+    torch = torch_mod
+    rng = np.random.default_rng(60 + variant)
+    counts = np.concatenate([rng.integers(0, 40, 60), rng.integers(200, 3000, 40), [0, 0, 1, 4, 5, 1024, 1025]]).astype(np.uint32)
+    streams = [oracle.encode(variant, GENERATORS["width_mix"](rng, int(c))) if c else np.zeros(0, dtype=np.uint8) for c in counts]
+    off = np.concatenate([[0], np.cumsum([s.size + 3 for s in streams])]).astype(np.int64)
+    buf = np.full(int(off[-1]) + 16, 0xEE, dtype=np.uint8)
+    for s, o in zip(streams, off[:-1]):
+        buf[o:o + s.size] = s
+    lengths = np.array([s.size for s in streams], dtype=np.int64)
+    # wrong in different ways
+    lengths[3] += 1
+    lengths[7] = max(int(lengths[7]) - 1, 0)
+    lengths[61] = 5                      # below the key bytes of a long list
+    lengths[100] = 2                     # count 0 with a length
+    k = 70                               # a tampered key byte of a long list
+    buf[off[k] + 10] ^= 0x0C
+    expect = np.array([oracle.validate(variant, buf[o:o + int(l)], int(c), int(l)) for o, l, c in zip(off[:-1], lengths, counts)],
+                      dtype=np.int32)
+    assert expect.sum() < counts.size and expect.sum() > counts.size // 2
+    got = codec.validate_batch(torch.from_numpy(buf).cuda(), torch.from_numpy(off[:-1].copy()).cuda(),
+                               torch.from_numpy(lengths).cuda(), to_dev(torch, counts), variant=variant)
+    assert np.array_equal(got.cpu().numpy(), expect), np.flatnonzero(got.cpu().numpy() != expect)
