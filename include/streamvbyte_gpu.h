@@ -54,6 +54,10 @@ int svbgpu_device_ok(void);
 /* Tuning knobs (process-wide, not thread-safe against running calls):
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
  *                               encoder carries through the look-back (default 4)
+ *   "encode_waves" = 4 | 8      wavefronts per workgroup of the encoder when
+ *                               "encode_tile" is 4 (default 8: a tile of 32 768
+ *                               values per look-back; the 0124 encoder always
+ *                               uses 4)
  *   "decode_shortcut" = 0|1     1 (default): the plain decoder copies wave tiles
  *                               (1024 values) whose keys are all zero straight
  *                               from their data bytes; 0: one code path for all

@@ -210,13 +210,14 @@ inline unsigned batch_grid(uint32_t nstreams) {
   return (unsigned)std::max<unsigned long long>(fill, (blocks + g_batch_lists_per_wave - 1) / g_batch_lists_per_wave);
 }
 unsigned g_debug = 0;  // timing-only ablations (wrong results!), see svbgpu_set_option
+int g_encode_waves = 8;  // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8); see svbgpu_set_option
 int g_encode_qw = 4;  // wave tiles per wave in k_encode (1, 2 or 4); see svbgpu_set_option
 
-template <int V, bool D, bool Z, int QW, bool QUANT = false>
+template <int V, bool D, bool Z, int QW, bool QUANT = false, int NW = kWaves>
 void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                       uint64_t* d_written, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  constexpr unsigned long long kTileInts = (unsigned long long)kWaves * QW * kWtInts;
+  constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
   const unsigned full_tiles = (unsigned)(count / kTileInts);
   const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
   WsHeader* h = ws_hdr(ws);
@@ -225,10 +226,10 @@ void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint
   u64* stamps = (g_debug & 16u) && g_ws_bytes_hint >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
   if (full_tiles)
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT>), dim3(stream_grid(full_tiles, QW > 2 || V != V1234 ? 4 : 5)), dim3(kBlock),
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW>), dim3(stream_grid(full_tiles, NW == 8 ? 2 : (QW > 2 || V != V1234 ? 4 : 5))), dim3(NW * 64),
                        0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, g_debug, stamps);
   if (ragged)  // the one tile that runs past the end of the stream: same look-back words
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT>), dim3(1), dim3(kBlock), 0, st, d_in, count, full_tiles,
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, g_debug, stamps);
 }
 template <int V, bool D, bool Z>
@@ -236,6 +237,8 @@ void launch_encode(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_
                    uint64_t* d_written, hipStream_t st) {
   if (g_encode_qw == 1) launch_encode_qw<V, D, Z, 1>(d_in, count, d_out, prev, ws, d_written, st);
   else if (g_encode_qw == 2) launch_encode_qw<V, D, Z, 2>(d_in, count, d_out, prev, ws, d_written, st);
+  else if (g_encode_waves == 8 && V == V1234)  // 0124 on small-valued input is faster with the smaller tile
+    launch_encode_qw<V, D, Z, 4, false, V == V1234 ? 8 : kWaves>(d_in, count, d_out, prev, ws, d_written, st);
   else launch_encode_qw<V, D, Z, 4>(d_in, count, d_out, prev, ws, d_written, st);
 }
 template <int V, bool D, bool Z>
@@ -308,6 +311,11 @@ int svbgpu_set_option(const char* name, int value) {
   if (!std::strcmp(name, "decode_grid_per_cu")) {
     if (value < 0) return SVBGPU_EINVAL;
     g_decode_per_cu = value;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "encode_waves")) {
+    if (value != 4 && value != 8) return SVBGPU_EINVAL;
+    g_encode_waves = value;
     return SVBGPU_OK;
   }
   if (!std::strcmp(name, "encode_tile")) {
@@ -406,7 +414,7 @@ int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float
   std::memcpy(&bits, &scale, 4);
   const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
   if (variant == SVBGPU_1234)
-    launch_encode_qw<V1234, false, true, 4, true>(in, count, d_out, bits, ws, d_written, S(stream));
+    launch_encode_qw<V1234, false, true, 4, true, 8>(in, count, d_out, bits, ws, d_written, S(stream));
   else
     launch_encode_qw<V0124, false, true, 4, true>(in, count, d_out, bits, ws, d_written, S(stream));
   HIP_TRY(hipGetLastError());

@@ -326,13 +326,13 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // QUANT: the input holds float32; every value becomes (int32)rintf(x * scale) first
 // (scale travels as the bits of `prev`, which only DELTA uses otherwise) -- the
 // quantise step of gradient compression fused into the encoder's load.
-template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false>
-__global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
+template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves>
+__global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 ? 2 : (QW > 2 || V != V1234 ? 4 : 5))) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
     u64* __restrict__ stamps) {
-  __shared__ EncWaveLds s_lds[kWaves];
-  __shared__ u32 s_wave_tot[kWaves];
+  __shared__ EncWaveLds s_lds[NW];
+  __shared__ u32 s_wave_tot[NW];
   __shared__ u64 s_prefix;
   __shared__ u32 s_tile;
 
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
   // diagnostic build only (stamps != nullptr): wall-clock stamps per tile, 100 MHz
   if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 0] = __builtin_amdgcn_s_memrealtime();
   const u64 keylen = ((u64)count + 3) >> 2;
-  constexpr u64 kTileInts = (u64)kWaves * QW * kWtInts;
+  constexpr u64 kTileInts = (u64)NW * QW * kWtInts;
   const u64 wave_first = (u64)tile * kTileInts + (u64)wave * QW * kWtInts;  // first value of this wave
 
   // ---- pass 1: load, transform, classify -----------------------------------
@@ -433,7 +433,9 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
 
   // ---- tile offset: sum of the byte counts of all earlier tiles ---------------
   if (wave == 0) {
-    const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    u32 tile_tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[w];
     u64 excl = 0;
     u32 rounds = 0;
     if (!(dbg & 1u)) {
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(kBlock, !FULL ? 1 : (QW > 2 || V != V1234 ? 4 : 5))
     if (stamps && lane == 0) stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
       s_prefix = excl;
-      const u64 last_tile = keylen ? (keylen - 1) / ((u64)kWaves * QW * kWtKeys) : 0;
+      const u64 last_tile = keylen ? (keylen - 1) / ((u64)NW * QW * kWtKeys) : 0;
       if (tile == last_tile && written) *written = keylen + excl + tile_tot;
     }
   }

@@ -120,17 +120,19 @@ def test_zigzag_fused_and_plain(torch_mod, codec, oracle):
 def test_encoder_tile_sizes(torch_mod, codec, oracle):
     """Every tile size of the encoder knob gives the same bytes."""
     from streamvbyte_amd import DELTA
-    for i, n in enumerate([1, 4097, 16385, 65537, 262144 + 7, (1 << 20) + 3]):
+    for i, n in enumerate([1, 4097, 16385, 32769, 65537, 262144 + 7, (1 << 20) + 3]):
         v = gen("width_mix", n, 6000 + i)
         for variant, flags, prev in ((V1234, 0, 0), (V0124, 0, 0), (V1234, DELTA, 99)):
             expect = oracle.encode(variant, v, bool(flags), prev)
-            for qw in (1, 2, 4):
+            for qw, waves in ((1, 8), (2, 8), (4, 4), (4, 8)):
                 codec.lib.svbgpu_set_option(b"encode_tile", qw)
+                codec.lib.svbgpu_set_option(b"encode_waves", waves)
                 out, size = codec.encode(to_dev(torch_mod, v), variant=variant, flags=flags, prev=prev)
                 codec.check()
                 codec.lib.svbgpu_set_option(b"encode_tile", 4)
-                assert int(size.item()) == expect.size, (n, variant, flags, qw)
-                assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags, qw)
+                codec.lib.svbgpu_set_option(b"encode_waves", 8)
+                assert int(size.item()) == expect.size, (n, variant, flags, qw, waves)
+                assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags, qw, waves)
 
 
 def test_size_and_validate(torch_mod, codec, oracle):
