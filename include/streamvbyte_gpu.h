@@ -58,6 +58,9 @@ int svbgpu_device_ok(void);
  *                               "encode_tile" is 4 (default 8: a tile of 32 768
  *                               values per look-back; the 0124 encoder always
  *                               uses 4)
+ *   "scan_waves" = 4 | 8 | 16   wavefronts per workgroup of the running sum
+ *                               behind svbgpu_zigzag_delta_decode (default 16:
+ *                               a tile of 65 536 values per look-back)
  *   "decode_shortcut" = 0|1     1 (default): the plain decoder copies wave tiles
  *                               (1024 values) whose keys are all zero straight
  *                               from their data bytes; 0: one code path for all

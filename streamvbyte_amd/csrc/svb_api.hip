@@ -79,6 +79,7 @@ inline unsigned stream_grid(unsigned long long work_blocks, int per_cu) {
   return (unsigned)(work_blocks < cap ? (work_blocks ? work_blocks : 1) : cap);
 }
 
+int g_scan_waves = 16;  // waves per workgroup of k_running_sum (4, 8 or 16) and of k_delta_decode (4, else 8); see svbgpu_set_option
 int g_decode_per_cu = 0;  // decoders: workgroups per CU of a persistent grid, 0 = a workgroup per 4 wave tiles; see svbgpu_set_option
 
 inline WsHeader* ws_hdr(void* ws) { return reinterpret_cast<WsHeader*>(ws); }
@@ -144,6 +145,12 @@ template <int V, bool ZZ>
 void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
                          void* ws, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
+  if (g_scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
+    hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st, d_in,
+                       d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
+                       ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
+                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+  else
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
                      d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
                      ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
@@ -311,6 +318,11 @@ int svbgpu_set_option(const char* name, int value) {
   if (!std::strcmp(name, "decode_grid_per_cu")) {
     if (value < 0) return SVBGPU_EINVAL;
     g_decode_per_cu = value;
+    return SVBGPU_OK;
+  }
+  if (!std::strcmp(name, "scan_waves")) {
+    if (value != 4 && value != 8 && value != 16) return SVBGPU_EINVAL;
+    g_scan_waves = value;
     return SVBGPU_OK;
   }
   if (!std::strcmp(name, "encode_waves")) {
@@ -524,6 +536,17 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   rc = clear_lookback(count, ws, S(stream));
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
+  const u32 n_tiles8 = (u32)((L.n_wt + 31) / 32);  // 8 waves of 4 wave tiles per workgroup
+  const u32 n_tiles16 = (u32)((L.n_wt + 63) / 64);
+  if (g_scan_waves == 16)
+    hipLaunchKernelGGL((k_running_sum<true, 16>), dim3(stream_grid(n_tiles16, 1)), dim3(1024), 0, S(stream), d_in,
+                       reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles16, ws_hdr(ws),
+                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
+  else if (g_scan_waves == 8)
+    hipLaunchKernelGGL((k_running_sum<true, 8>), dim3(stream_grid(n_tiles8, 2)), dim3(512), 0, S(stream), d_in,
+                       reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles8, ws_hdr(ws),
+                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
+  else
   hipLaunchKernelGGL(k_running_sum<true>, dim3(stream_grid(L.n_tiles, 4)), dim3(kBlock), 0, S(stream), d_in,
                      reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, (u32)L.n_tiles, ws_hdr(ws),
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});

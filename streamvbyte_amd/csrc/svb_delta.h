@@ -40,13 +40,16 @@ __device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[4][4], int lane) {
 // Workgroup-level part shared by the delta decoder and the plain scan kernel:
 // exchange wave totals, publish the tile total, look back, return the value to
 // add to every element of this wave.
+template <int NW = kWaves>
 __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 seed, int lane,
                                                  int wave, WsHeader* hdr, const LbWords& lb,
                                                  u32* s_wave_tot, u32* s_prefix) {
   if (lane == 0) s_wave_tot[wave] = wave_tot;
   __syncthreads();
   if (wave == 0) {
-    const u32 tile_tot = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+    u32 tile_tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[w];
     const u32 excl = seed + (u32)lb2_exclusive_prefix<1>(lb, tile, tile_tot, lane, &hdr->error);
     if (lane == 0) *s_prefix = excl;
   }
@@ -56,13 +59,13 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
   return add;
 }
 
-template <int V, bool ZZ>
-__global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
+template <int V, bool ZZ, int NW = kWaves>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
     const u64* __restrict__ super_off, const u32* __restrict__ wt_rel, WsHeader* __restrict__ hdr,
     LbWords lb, u64* __restrict__ consumed) {
-  __shared__ WaveLds s_lds[kWaves];
-  __shared__ u32 s_wave_tot[kWaves];
+  __shared__ WaveLds s_lds[NW];
+  __shared__ u32 s_wave_tot[NW];
   __shared__ u32 s_prefix;
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
   const u64 keylen = ((u64)count + 3) >> 2;
   const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
   const u8* data_base = in + keylen;
-  const u32 wt0 = tile * kLbWt + wave * 4;
+  const u32 wt0 = tile * (NW * 4) + wave * 4;  // NW waves of 4 wave tiles: NW * 4096 values per look-back tile
 
   uint4 v[4][4];
   // keys and offsets of the wave's 4 wave tiles up front
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_delta_decode(
     }
   }
   const u32 wave_tot = wave_running_sums(v, lane);
-  const u32 add = tile_value_prefix(wave_tot, tile, prev, lane, wave, hdr, lb, s_wave_tot,
-                                    &s_prefix);
+  const u32 add = tile_value_prefix<NW>(wave_tot, tile, prev, lane, wave, hdr, lb, s_wave_tot,
+                                        &s_prefix);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -235,12 +238,13 @@ __global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__
 
 // Plain inclusive running sum out[i] = seed + sum_{j<=i} f(in[j]), f = identity
 // or un-zigzag (zigzag_delta_decode).  8 B per value.
-template <bool ZZ>
-__global__ __launch_bounds__(kBlock, 4) void k_running_sum(const u32* __restrict__ in,
+// NW waves per workgroup, each with 4 wave tiles: a tile of the look-back holds NW * 4096 values.
+template <bool ZZ, int NW = kWaves>
+__global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restrict__ in,
                                                            u32* __restrict__ out, u32 count,
                                                            u32 seed, u32 n_tiles,
                                                            WsHeader* __restrict__ hdr, LbWords lb) {
-  __shared__ u32 s_wave_tot[kWaves];
+  __shared__ u32 s_wave_tot[NW];
   __shared__ u32 s_prefix;
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_running_sum(const u32* __restrict
   __syncthreads();
   const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
   if (tile >= n_tiles) break;
-  const u64 wave_first = ((u64)tile * kLbWt + (u64)wave * 4) * kWtInts;
+  const u64 wave_first = ((u64)tile * (NW * 4) + (u64)wave * 4) * kWtInts;
   uint4 v[4][4];
   const bool whole = wave_first + 4u * kWtInts <= count;  // wave-uniform: all 4096 values of this wave exist
   if (whole) {
@@ -287,8 +291,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_running_sum(const u32* __restrict
       }
   }
   const u32 wave_tot = wave_running_sums(v, lane);
-  const u32 add = tile_value_prefix(wave_tot, tile, seed, lane, wave, hdr, lb, s_wave_tot,
-                                    &s_prefix);
+  const u32 add = tile_value_prefix<NW>(wave_tot, tile, seed, lane, wave, hdr, lb, s_wave_tot,
+                                        &s_prefix);
   if (whole) {
     uint4* dst = reinterpret_cast<uint4*>(out + wave_first);
 #pragma unroll

@@ -327,7 +327,7 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // (scale travels as the bits of `prev`, which only DELTA uses otherwise) -- the
 // quantise step of gradient compression fused into the encoder's load.
 template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves>
-__global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 ? 2 : (QW > 2 || V != V1234 ? 4 : 5))) void k_encode(
+__global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
     u64* __restrict__ stamps) {
