@@ -895,11 +895,12 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
     d_out = static_cast<uint32_t*>(c->b);
   }
   // Differential decode: the stream's size is known here, so the faster of the
-  // two decoders can be picked per call.  Two passes re-read keys and data, which
-  // costs little for narrow deltas (posting-list gaps) and too much for wide
-  // ones: 0.36 ms against 0.43 ms at 1 data byte per value, 0.64 ms against
-  // 0.53 ms at 3.75 (2^28 values).
-  const int lookback = (flags & SVBGPU_DELTA) && 4 * total > 9 * (uint64_t)count;  // > 2.25 data bytes per value
+  // two decoders can be picked per call.  Two passes re-read keys and data; that
+  // pays when nearly every wave tile takes the all-zero-keys shortcut (dense
+  // posting-list gaps, 1 data byte per value: 0.33 ms against 0.37 ms at 2^28
+  // values) and no longer at 1.5 data bytes per value (0.47 against 0.42 ms) or
+  // beyond (3.75: 0.59 against 0.46 ms).
+  const int lookback = (flags & SVBGPU_DELTA) && 64 * total > 65 * (uint64_t)count;  // > 1 + 1/64 data bytes per value
   rc = run_decode(variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream, lookback);
   if (rc) die("decode", rc);
   if (!out_dev) COPY_OR_DIE(copy_out(c, out, d_out, (size_t)count * 4));
