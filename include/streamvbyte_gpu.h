@@ -33,6 +33,12 @@ extern "C" {
 #define SVBGPU_ZIGZAG 2u /* encode: values are int32, zigzag-mapped before coding;
                             decode: un-zigzag after decoding (fuses zigzag_encode/
                             zigzag_decode into the codec pass)                      */
+#define SVBGPU_WIDE 4u   /* svbgpu_decode / svbgpu_decode_run with SVBGPU_DELTA only,
+                            a hint that changes speed, never results: most deltas
+                            take more than one byte, use the single-pass decoder
+                            (as option "delta_decode_lookback" = 1 does for all
+                            calls).  The two-pass default suits dense posting
+                            lists, whose gaps fit one byte.                        */
 /* Both variants take every combination of the flags.  DELTA | ZIGZAG codes
  * zigzag(in[i] - in[i-1]), i.e. zigzag_delta_encode (reference
  * src/streamvbyte_zigzag.c:13-18) followed by the encoder, in one pass; the

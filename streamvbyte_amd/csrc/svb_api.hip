@@ -350,6 +350,8 @@ int svbgpu_check_status(const void* d_workspace, void* stream) {
 
 int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
                   uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed, void* stream) {
+  const int wide = (flags & SVBGPU_WIDE) ? 1 : -1;
+  flags &= ~SVBGPU_WIDE;
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
     if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
@@ -361,7 +363,7 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
   if (rc) return rc;
   rc = build_directory(variant, d_in, count, ws, S(stream));
   if (rc) return rc;
-  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), wide);
 }
 
 int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* ws, size_t ws_bytes,
@@ -378,6 +380,8 @@ int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* w
 int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out,
                       uint32_t count, uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed,
                       void* stream) {
+  const int wide = (flags & SVBGPU_WIDE) ? 1 : -1;
+  flags &= ~SVBGPU_WIDE;
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
     if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
@@ -387,7 +391,7 @@ int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), wide);
 }
 
 int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,

@@ -75,9 +75,10 @@ def test_delta_matches_oracle(torch_mod, codec, oracle, kind):
         codec.check()
         assert int(size.item()) == s.size
         assert np.array_equal(out[: s.size].cpu().numpy(), s), (kind, n)
-        for lookback in (0, 1):  # two-pass (default) and single-pass look-back decoders
-            codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
-            dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA, prev=prev)
+        for lookback in (0, 1, 2):  # two-pass (default), single-pass look-back by option, by the SVBGPU_WIDE hint
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", int(lookback == 1))
+            dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA | (4 if lookback == 2 else 0),
+                                     prev=prev)
             codec.check()
             codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
             assert int(used.item()) == s.size
