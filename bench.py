@@ -362,9 +362,10 @@ def main():
         d3b = (int(z3.item()) - (n3b + 3) // 4) / n3b
         o3 = out[:n3b]
         ms_e, _ = event_ms(torch, lambda: codec.encode(post, out=enc_out, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF), it)
-        # gaps wider than a byte: the caller says so (SVBGPU_WIDE) and gets the single-pass decoder
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)   # the two-pass decoder, for comparison
         ms_d2, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
-        ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA | svb.WIDE, prev=0xDEADBEEF), it)
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+        ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
         codec.check()
         extra["delta_mixed_gaps"] = {"n": n3b, "data_bytes_per_value": round(d3b, 4), "prev": "0xDEADBEEF",
                                      "parity": bool(torch.equal(o3, post)),

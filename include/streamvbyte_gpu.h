@@ -33,12 +33,6 @@ extern "C" {
 #define SVBGPU_ZIGZAG 2u /* encode: values are int32, zigzag-mapped before coding;
                             decode: un-zigzag after decoding (fuses zigzag_encode/
                             zigzag_decode into the codec pass)                      */
-#define SVBGPU_WIDE 4u   /* svbgpu_decode / svbgpu_decode_run with SVBGPU_DELTA only,
-                            a hint that changes speed, never results: most deltas
-                            take more than one byte, use the single-pass decoder
-                            (as option "delta_decode_lookback" = 1 does for all
-                            calls).  The two-pass default suits dense posting
-                            lists, whose gaps fit one byte.                        */
 /* Both variants take every combination of the flags.  DELTA | ZIGZAG codes
  * zigzag(in[i] - in[i-1]), i.e. zigzag_delta_encode (reference
  * src/streamvbyte_zigzag.c:13-18) followed by the encoder, in one pass; the
@@ -65,13 +59,17 @@ int svbgpu_device_ok(void);
  *                               values per look-back; the 0124 encoder always
  *                               uses 4)
  *   "scan_waves" = 4 | 8 | 16   wavefronts per workgroup of the running sum
- *                               behind svbgpu_zigzag_delta_decode (default 16:
- *                               a tile of 65 536 values per look-back)
+ *                               behind svbgpu_zigzag_delta_decode and of the
+ *                               single-pass differential decoder (default 16:
+ *                               a tile of 65 536 values per look-back; streams
+ *                               below 2^23 values are decoded with 8)
  *   "decode_shortcut" = 0|1     1 (default): the plain decoder copies wave tiles
  *                               (1024 values) whose keys are all zero straight
  *                               from their data bytes; 0: one code path for all
- *   "delta_decode_lookback" = 0|1  0 (default): differential decode in two
- *                               streaming passes; 1: single pass with look-back
+ *   "delta_decode_lookback" = 0|1  1 (default): differential decode in a single
+ *                               pass with look-back; 0: two streaming passes
+ *                               (value sums first), no waiting between
+ *                               workgroups
  *   "decode_grid_per_cu" = k    decoders: 0 (default) a workgroup per 4096
  *                               values, handed out in order by the hardware;
  *                               k > 0: a persistent grid of k workgroups per CU

@@ -19,7 +19,7 @@ import numpy as np
 from ._lib import load, LIB_PATH, SIGNATURES  # noqa: F401
 
 V1234, V0124 = 0, 1
-DELTA, ZIGZAG, WIDE = 1, 2, 4
+DELTA, ZIGZAG = 1, 2
 STREAMVBYTE_PADDING = 16
 
 

@@ -145,7 +145,12 @@ template <int V, bool ZZ>
 void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
                          void* ws, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  if (g_scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
+  if (g_scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
+    hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024), 0, st, d_in,
+                       d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
+                       ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
+                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+  else if (g_scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st, d_in,
                        d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
                        ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
@@ -157,7 +162,7 @@ void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, u
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
 }
 
-int g_delta_lookback = 0;  // 1: single-pass look-back delta decoder, 0: two-pass (default)
+int g_delta_lookback = 1;  // 1 (default): single-pass look-back differential decoder, 0: two streaming passes
 
 template <int V, bool ZZ>
 void launch_delta_decode2(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
@@ -350,8 +355,6 @@ int svbgpu_check_status(const void* d_workspace, void* stream) {
 
 int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
                   uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed, void* stream) {
-  const int wide = (flags & SVBGPU_WIDE) ? 1 : -1;
-  flags &= ~SVBGPU_WIDE;
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
     if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
@@ -363,7 +366,7 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
   if (rc) return rc;
   rc = build_directory(variant, d_in, count, ws, S(stream));
   if (rc) return rc;
-  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), wide);
+  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
 }
 
 int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* ws, size_t ws_bytes,
@@ -380,8 +383,6 @@ int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* w
 int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out,
                       uint32_t count, uint32_t prev, void* ws, size_t ws_bytes, uint64_t* d_consumed,
                       void* stream) {
-  const int wide = (flags & SVBGPU_WIDE) ? 1 : -1;
-  flags &= ~SVBGPU_WIDE;
   if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
     if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
@@ -391,7 +392,7 @@ int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), wide);
+  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
 }
 
 int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,
@@ -898,18 +899,11 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
     grow(c->b, c->b_cap, (size_t)count * 4);
     d_out = static_cast<uint32_t*>(c->b);
   }
-  // Differential decode: the stream's size is known here, so the faster of the
-  // two decoders can be picked per call.  Two passes re-read keys and data; that
-  // pays when nearly every wave tile takes the all-zero-keys shortcut (dense
-  // posting-list gaps, 1 data byte per value: 0.33 ms against 0.37 ms at 2^28
-  // values) and no longer at 1.5 data bytes per value (0.47 against 0.42 ms) or
-  // beyond (3.75: 0.59 against 0.46 ms).
-  const int lookback = (flags & SVBGPU_DELTA) && 64 * total > 65 * (uint64_t)count;  // > 1 + 1/64 data bytes per value
-  rc = run_decode(variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream, lookback);
+  rc = run_decode(variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream);
   if (rc) die("decode", rc);
   if (!out_dev) COPY_OR_DIE(copy_out(c, out, d_out, (size_t)count * 4));
   const uint64_t n = fetch_u64(c, c->d_res);
-  if (lookback) check_scan(c);  // only the look-back decoder (which clears it first) uses the error word
+  if ((flags & SVBGPU_DELTA) && g_delta_lookback) check_scan(c);  // only the look-back decoder (which clears it first) uses the error word
   return (size_t)n;
 }
 

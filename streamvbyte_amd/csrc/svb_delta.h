@@ -60,7 +60,7 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
 }
 
 template <int V, bool ZZ, int NW = kWaves>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 3) void k_delta_decode(
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
     const u64* __restrict__ super_off, const u32* __restrict__ wt_rel, WsHeader* __restrict__ hdr,
     LbWords lb, u64* __restrict__ consumed) {

@@ -288,11 +288,8 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
     if (reinterpret_cast<const uint32_t*>(c->h_res + 1)[0] != 1u) return SVBFRAME_EINVALID;
     int r = build_directory(f.inf.variant, static_cast<const uint8_t*>(c->a), f.inf.count, c->ws, c->stream);
     if (r) return r;
-    // the header tells the data bytes per value: pick the differential decoder that suits them (see decode_any)
-    const uint64_t data_bytes = f.inf.stream_bytes - ((uint64_t)f.inf.count + 3) / 4;
-    const int lookback = (f.inf.flags & SVBGPU_DELTA) && 64 * data_bytes > 65 * (uint64_t)f.inf.count;
     r = run_decode(f.inf.variant, f.inf.flags, static_cast<const uint8_t*>(c->a), static_cast<uint32_t*>(c->b),
-                   f.inf.count, f.inf.prev, c->ws, nullptr, c->stream, lookback);
+                   f.inf.count, f.inf.prev, c->ws, nullptr, c->stream);
     if (r) return r;
     return S.copy_down(i, out + f.voff, c->b, (size_t)f.inf.count * 4);
   };

@@ -75,12 +75,13 @@ def test_delta_matches_oracle(torch_mod, codec, oracle, kind):
         codec.check()
         assert int(size.item()) == s.size
         assert np.array_equal(out[: s.size].cpu().numpy(), s), (kind, n)
-        for lookback in (0, 1, 2):  # two-pass (default), single-pass look-back by option, by the SVBGPU_WIDE hint
-            codec.lib.svbgpu_set_option(b"delta_decode_lookback", int(lookback == 1))
-            dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA | (4 if lookback == 2 else 0),
-                                     prev=prev)
+        for lookback, waves in ((0, 16), (1, 16), (1, 8), (1, 4)):  # two-pass and single-pass look-back decoders
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
+            codec.lib.svbgpu_set_option(b"scan_waves", waves)
+            dec, used = codec.decode(dev_stream(torch_mod, s), n, variant=V1234, flags=DELTA, prev=prev)
             codec.check()
-            codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+            codec.lib.svbgpu_set_option(b"scan_waves", 16)
             assert int(used.item()) == s.size
             assert np.array_equal(to_np(dec, np.uint32), v), (kind, n, lookback)
 
@@ -383,7 +384,7 @@ def test_all_small_wave_tiles(torch_mod, codec, oracle, variant):
                 codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
                 dec, used = codec.decode(dev_stream(torch_mod, expect, misalign=n % 3), n, variant=variant, flags=flags, prev=prev)
                 codec.check()
-                codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+                codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
                 assert int(used.item()) == expect.size
                 assert np.array_equal(to_np(dec, np.uint32), src), (n, flags, lookback)
 
@@ -403,7 +404,7 @@ def test_decoders_write_exactly_count_values(torch_mod, codec, oracle):
                 codec.lib.svbgpu_set_option(b"delta_decode_lookback", lookback)
                 codec.decode(dev_stream(torch, s), n, out=big[guard:guard + n], variant=variant, flags=flags,
                              prev=9 if flags & DELTA else 0)
-                codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+                codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
                 h = big.cpu().numpy().view(np.uint32)
                 assert np.array_equal(h[guard:guard + n], v), (n, variant, flags)
                 assert (h[:guard] == 0x5A5A5A5A).all() and (h[guard + n:] == 0x5A5A5A5A).all(), (n, variant, flags)

@@ -133,5 +133,5 @@ while time.time() < t_end:
         assert int(u.item()) == sa.size and int(k.item()) == exp_hits.size, ("intersect count", m, pv) + tag
         assert np.array_equal(to_np(o[: exp_hits.size], np.uint32), exp_hits), ("intersect", m, pv) + tag
 codec.lib.svbgpu_set_option(b"encode_tile", 4)
-codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
+codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
 print(f"fuzz ok: {it} cases, seed {seed}")

@@ -83,20 +83,20 @@ if want("delta"):
     ops["delta_encode"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
     ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
 
-    def dd_lookback():
-        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
-        codec.decode(s3, n, out=out, flags=svb.DELTA)
+    def dd_twopass():
         codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
-    ops["delta_decode_lookback"] = (dd_lookback, (4.25 + d3) * n)
+        codec.decode(s3, n, out=out, flags=svb.DELTA)
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+    ops["delta_decode_twopass"] = (dd_twopass, (4.25 + d3) * n)
     sm, zm = codec.encode(values, flags=svb.DELTA)
     sm = sm.clone()
     ops["delta_decode_mixed"] = (lambda: codec.decode(sm, n, out=out, flags=svb.DELTA), (int(zm.item()) + 4.0 * n))
 
-    def ddm_lookback():
-        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
-        codec.decode(sm, n, out=out, flags=svb.DELTA)
+    def ddm_twopass():
         codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
-    ops["delta_decode_mixed_lookback"] = (ddm_lookback, (int(zm.item()) + 4.0 * n))
+        codec.decode(sm, n, out=out, flags=svb.DELTA)
+        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+    ops["delta_decode_mixed_twopass"] = (ddm_twopass, (int(zm.item()) + 4.0 * n))
 if want("zz"):
     n4 = min(n, 1 << 26)
     g = torch.Generator(device=dev); g.manual_seed(9)
