@@ -39,7 +39,38 @@ def parse():
     ap.add_argument("--log2n", type=int, default=28)
     ap.add_argument("--quick", action="store_true", help="skip the secondary workloads and the CPU baseline")
     ap.add_argument("--lists", type=int, default=1 << 20, help="posting lists in the batched workload (whole job)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --stub)")
+    ap.add_argument("--stub", action="store_true",
+                    help="rank plumbing only: every rank times a host memcpy instead of the GPU workload "
+                         "(no GPU needed; used by the CPU test of the launcher)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh
+    rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in their environment, exactly what torch.distributed.run sets) and wait for
+    them.  This parent never touches the GPU -- it has not even imported torch --
+    so no process that initialised HIP is ever replaced or forked.  Rank 0
+    prints the one JSON line on the stdout the children inherit."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def gen_width_mix(torch, n, seed, device):
@@ -205,14 +236,59 @@ def gen_posting_lists(torch, counts_np, seed, device):
     return counts.to(torch.int32), voff, vals32
 
 
+def stub_rank(a, rank, world):
+    """The rank plumbing of the real run (process group, barriers around the timed
+    region, max over ranks, one JSON line from rank 0) around a host memcpy.
+    Measures nothing about the codec; exists so that the N-rank path can be
+    exercised without GPUs."""
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
+    n = 1 << min(a.log2n, 20)
+    src, dst = np.arange(n, dtype=np.uint32), np.empty(n, dtype=np.uint32)
+    for _ in range(a.warmup):
+        np.copyto(dst, src)
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        np.copyto(dst, src)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks_seen = torch.tensor([1], dtype=torch.int64)
+    if dist:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks_seen)
+    t = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "host memcpy GB/s (launcher stub, not the codec)", "stub": True,
+                          "value": round(4.0 * n * a.steps * world / t / 1e9, 3), "unit": "GB/s", "n_gpus": world,
+                          "ranks_seen": int(ranks_seen.item()), "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(t / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                          "config": {"workload": "launcher stub"}}), flush=True)
+    if dist:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     a = parse()
-    import torch
-    import streamvbyte_amd as svb
-
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)  # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.stub:
+        return stub_rank(a, rank, world)
+    if a.backend != "nccl":
+        sys.exit("--backend gloo is for --stub only: the codec runs on GPUs, ranks talk over RCCL")
+    import torch
+    import streamvbyte_amd as svb
+
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
