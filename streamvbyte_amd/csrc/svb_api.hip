@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,8 +80,42 @@ inline unsigned stream_grid(unsigned long long work_blocks, int per_cu) {
   return (unsigned)(work_blocks < cap ? (work_blocks ? work_blocks : 1) : cap);
 }
 
-int g_scan_waves = 16;  // waves per workgroup of k_running_sum (4, 8 or 16) and of k_delta_decode (4, else 8); see svbgpu_set_option
-int g_decode_per_cu = 0;  // decoders: workgroups per CU of a persistent grid, 0 = a workgroup per 4 wave tiles; see svbgpu_set_option
+// Tuning knobs (svbgpu_set_option): process-wide atomics, read ONCE at the top of
+// an API call into a plain struct that travels down to the launches, so a call
+// never runs on half of a change made by another thread and what a call checks
+// afterwards matches what it launched.
+struct Options {
+  int scan_waves;        // waves per workgroup of k_running_sum (4, 8 or 16) and of k_delta_decode
+  int decode_per_cu;     // decoders: workgroups per CU of a persistent grid, 0 = a workgroup per 4 wave tiles
+  int decode_shortcut;   // plain decoder: shortcut for wave tiles of all-zero keys
+  int delta_lookback;    // 1: single-pass look-back differential decoder, 0: two streaming passes
+  int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8)
+  int encode_qw;         // wave tiles per wave in k_encode (1, 2 or 4)
+  int batch_lists_per_wave;  // batched kernels: lists per wave of a launch, 0 = one grid that fills the device
+  unsigned debug;        // timing-only ablations (wrong results!)
+  int zigzag_piece;      // values per device scan of the host-pointer zigzag_delta_decode
+  int host_serialize;    // host-pointer calls: one at a time per device inside the runtime
+  int host_stage_pageable;  // host-pointer calls: pageable caller memory moves through page-locked chunks
+};
+std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
+    o_encode_qw{4}, o_batch_lists_per_wave{8}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_serialize{1},
+    o_host_stage_pageable{1};
+inline Options options() {
+  Options o;
+  const auto rl = std::memory_order_relaxed;
+  o.scan_waves = o_scan_waves.load(rl);
+  o.decode_per_cu = o_decode_per_cu.load(rl);
+  o.decode_shortcut = o_decode_shortcut.load(rl);
+  o.delta_lookback = o_delta_lookback.load(rl);
+  o.encode_waves = o_encode_waves.load(rl);
+  o.encode_qw = o_encode_qw.load(rl);
+  o.batch_lists_per_wave = o_batch_lists_per_wave.load(rl);
+  o.debug = (unsigned)o_debug.load(rl);
+  o.zigzag_piece = o_zigzag_piece.load(rl);
+  o.host_serialize = o_host_serialize.load(rl);
+  o.host_stage_pageable = o_host_stage_pageable.load(rl);
+  return o;
+}
 
 inline WsHeader* ws_hdr(void* ws) { return reinterpret_cast<WsHeader*>(ws); }
 template <class T>
@@ -126,15 +161,12 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   return SVBGPU_OK;
 }
 
-size_t g_zigzag_piece = 1u << 31;  // values per device scan of the host-pointer zigzag_delta_decode
-int g_decode_shortcut = 1;  // plain decoder: shortcut for wave tiles of all-zero keys, see svbgpu_set_option
-
 template <int V, bool ZZ>
-void launch_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, void* ws,
+void launch_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint32_t count, void* ws,
                    uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, g_decode_per_cu);
-  if (g_decode_shortcut)
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, o.decode_per_cu);
+  if (o.decode_shortcut)
     hipLaunchKernelGGL((k_decode<V, ZZ, true>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
                        ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed, 0u);
   else
@@ -142,15 +174,15 @@ void launch_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, void* w
                        ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed, 0u);
 }
 template <int V, bool ZZ>
-void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
+void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
                          void* ws, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  if (g_scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
+  if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
     hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024), 0, st, d_in,
                        d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
                        ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
-  else if (g_scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
+  else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st, d_in,
                        d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
                        ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
@@ -162,13 +194,11 @@ void launch_delta_decode(const uint8_t* d_in, uint32_t* d_out, uint32_t count, u
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
 }
 
-int g_delta_lookback = 1;  // 1 (default): single-pass look-back differential decoder, 0: two streaming passes
-
 template <int V, bool ZZ>
-void launch_delta_decode2(const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
+void launch_delta_decode2(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
                           void* ws, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, g_decode_per_cu);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, o.decode_per_cu);
   u64* super_off = ws_at<u64>(ws, L.off_super_off);
   u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
   u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
@@ -182,52 +212,46 @@ void launch_delta_decode2(const uint8_t* d_in, uint32_t* d_out, uint32_t count, 
 }
 
 // decode with the directory already in the workspace
-// delta_lookback: 1 = single-pass look-back differential decoder, 0 = two-pass, -1 = the process-wide option
-int run_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
-               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st, int delta_lookback = -1) {
+int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
+               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st) {
   const bool zz = flags & SVBGPU_ZIGZAG, delta = flags & SVBGPU_DELTA;
   const bool v0 = variant == SVBGPU_1234;
   if (!delta) {
-    if (v0) { if (zz) launch_decode<V1234, true>(d_in, d_out, count, ws, d_consumed, st);
-              else    launch_decode<V1234, false>(d_in, d_out, count, ws, d_consumed, st); }
-    else    { if (zz) launch_decode<V0124, true>(d_in, d_out, count, ws, d_consumed, st);
-              else    launch_decode<V0124, false>(d_in, d_out, count, ws, d_consumed, st); }
-  } else if (delta_lookback < 0 ? g_delta_lookback : delta_lookback) {
+    if (v0) { if (zz) launch_decode<V1234, true>(o, d_in, d_out, count, ws, d_consumed, st);
+              else    launch_decode<V1234, false>(o, d_in, d_out, count, ws, d_consumed, st); }
+    else    { if (zz) launch_decode<V0124, true>(o, d_in, d_out, count, ws, d_consumed, st);
+              else    launch_decode<V0124, false>(o, d_in, d_out, count, ws, d_consumed, st); }
+  } else if (o.delta_lookback) {
     int rc = clear_lookback(count, ws, st);
     if (rc) return rc;
-    if (v0) { if (zz) launch_delta_decode<V1234, true>(d_in, d_out, count, prev, ws, d_consumed, st);
-              else    launch_delta_decode<V1234, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
-    else    { if (zz) launch_delta_decode<V0124, true>(d_in, d_out, count, prev, ws, d_consumed, st);
-              else    launch_delta_decode<V0124, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
+    if (v0) { if (zz) launch_delta_decode<V1234, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode<V1234, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
+    else    { if (zz) launch_delta_decode<V0124, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode<V0124, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
   } else {
-    if (v0) { if (zz) launch_delta_decode2<V1234, true>(d_in, d_out, count, prev, ws, d_consumed, st);
-              else    launch_delta_decode2<V1234, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
-    else    { if (zz) launch_delta_decode2<V0124, true>(d_in, d_out, count, prev, ws, d_consumed, st);
-              else    launch_delta_decode2<V0124, false>(d_in, d_out, count, prev, ws, d_consumed, st); }
+    if (v0) { if (zz) launch_delta_decode2<V1234, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode2<V1234, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
+    else    { if (zz) launch_delta_decode2<V0124, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
+              else    launch_delta_decode2<V0124, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
   }
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
 
-size_t g_ws_bytes_hint = 0;
 // Batched kernels: a wave takes about this many lists, so that a launch has many more workgroups than fit
 // the device and the hardware hands them out as earlier ones finish.  Lists differ in length by orders of
 // magnitude; lists strided over a grid that just fills the device left some waves with 1.3x the average
 // work.  0 = such a persistent grid.  See svbgpu_set_option.
-unsigned g_batch_lists_per_wave = 8;
-inline unsigned batch_grid(uint32_t nstreams) {
+inline unsigned batch_grid(const Options& o, uint32_t nstreams) {
   const unsigned long long blocks = ((unsigned long long)nstreams + kWaves - 1) / kWaves;
   const unsigned fill = stream_grid(blocks, 8);
-  if (g_batch_lists_per_wave == 0) return fill;
-  return (unsigned)std::max<unsigned long long>(fill, (blocks + g_batch_lists_per_wave - 1) / g_batch_lists_per_wave);
+  if (o.batch_lists_per_wave <= 0) return fill;
+  return (unsigned)std::max<unsigned long long>(fill, (blocks + o.batch_lists_per_wave - 1) / o.batch_lists_per_wave);
 }
-unsigned g_debug = 0;  // timing-only ablations (wrong results!), see svbgpu_set_option
-int g_encode_waves = 8;  // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8); see svbgpu_set_option
-int g_encode_qw = 4;  // wave tiles per wave in k_encode (1, 2 or 4); see svbgpu_set_option
 
 template <int V, bool D, bool Z, int QW, bool QUANT = false, int NW = kWaves>
-void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
-                      uint64_t* d_written, hipStream_t st) {
+void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
+                      size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
   const WsLayout L = ws_layout(count);
   constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
   const unsigned full_tiles = (unsigned)(count / kTileInts);
@@ -235,23 +259,23 @@ void launch_encode_qw(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint
   WsHeader* h = ws_hdr(ws);
   const LbWords status{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
-  u64* stamps = (g_debug & 16u) && g_ws_bytes_hint >= L.total + 40ull * (full_tiles + 2)
+  u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
   if (full_tiles)
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW>), dim3(stream_grid(full_tiles, NW == 8 ? 2 : (QW > 2 || V != V1234 ? 4 : 5))), dim3(NW * 64),
-                       0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, g_debug, stamps);
+                       0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps);
   if (ragged)  // the one tile that runs past the end of the stream: same look-back words
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
-                       d_out, prev, h, status, d_written, g_debug, stamps);
+                       d_out, prev, h, status, d_written, o.debug, stamps);
 }
 template <int V, bool D, bool Z>
-void launch_encode(const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
-                   uint64_t* d_written, hipStream_t st) {
-  if (g_encode_qw == 1) launch_encode_qw<V, D, Z, 1>(d_in, count, d_out, prev, ws, d_written, st);
-  else if (g_encode_qw == 2) launch_encode_qw<V, D, Z, 2>(d_in, count, d_out, prev, ws, d_written, st);
-  else if (g_encode_waves == 8 && V == V1234)  // 0124 on small-valued input is faster with the smaller tile
-    launch_encode_qw<V, D, Z, 4, false, V == V1234 ? 8 : kWaves>(d_in, count, d_out, prev, ws, d_written, st);
-  else launch_encode_qw<V, D, Z, 4>(d_in, count, d_out, prev, ws, d_written, st);
+void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
+                   size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
+  if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (o.encode_waves == 8 && V == V1234)  // 0124 on small-valued input is faster with the smaller tile
+    launch_encode_qw<V, D, Z, 4, false, V == V1234 ? 8 : kWaves>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else launch_encode_qw<V, D, Z, 4>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
 }
 template <int V, bool D, bool Z>
 void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* d_bytes,
@@ -290,6 +314,7 @@ const char* svbgpu_strerror(int code) {
     case SVBGPU_EWORKSPACE: return "workspace missing, misaligned or too small";
     case SVBGPU_EHIP: return hipGetErrorString(g_last_hip_error);
     case SVBGPU_ESCAN: return "device scan gave up waiting on another workgroup";
+    case SVBGPU_ETOOBIG: return "count beyond what the library's static scratch is sized for";
     default: return "unknown error";
   }
 }
@@ -298,48 +323,26 @@ int svbgpu_device_ok(void) { return dev_info().ok ? 1 : 0; }
 
 int svbgpu_set_option(const char* name, int value) {
   if (!name) return SVBGPU_EINVAL;
-  if (!std::strcmp(name, "debug_ablate")) {
-    g_debug = (unsigned)value;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "zigzag_piece")) {
-    if (value < 1) return SVBGPU_EINVAL;
-    g_zigzag_piece = (size_t)value;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "decode_shortcut")) {
-    g_decode_shortcut = value != 0;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "delta_decode_lookback")) {
-    g_delta_lookback = value != 0;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "batch_lists_per_wave")) {
-    if (value < 0) return SVBGPU_EINVAL;
-    g_batch_lists_per_wave = (unsigned)value;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "decode_grid_per_cu")) {
-    if (value < 0) return SVBGPU_EINVAL;
-    g_decode_per_cu = value;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "scan_waves")) {
-    if (value != 4 && value != 8 && value != 16) return SVBGPU_EINVAL;
-    g_scan_waves = value;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "encode_waves")) {
-    if (value != 4 && value != 8) return SVBGPU_EINVAL;
-    g_encode_waves = value;
-    return SVBGPU_OK;
-  }
-  if (!std::strcmp(name, "encode_tile")) {
-    if (value != 1 && value != 2 && value != 4) return SVBGPU_EINVAL;
-    g_encode_qw = value;
-    return SVBGPU_OK;
-  }
+  struct Knob { const char* name; std::atomic<int>* cell; bool (*ok)(int); };
+  static const Knob knobs[] = {
+      {"debug_ablate", &o_debug, [](int) { return true; }},
+      {"zigzag_piece", &o_zigzag_piece, [](int v) { return v >= 1; }},
+      {"decode_shortcut", &o_decode_shortcut, [](int v) { return v == 0 || v == 1; }},
+      {"delta_decode_lookback", &o_delta_lookback, [](int v) { return v == 0 || v == 1; }},
+      {"batch_lists_per_wave", &o_batch_lists_per_wave, [](int v) { return v >= 0; }},
+      {"decode_grid_per_cu", &o_decode_per_cu, [](int v) { return v >= 0; }},
+      {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
+      {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
+      {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
+      {"host_serialize", &o_host_serialize, [](int v) { return v == 0 || v == 1; }},
+      {"host_stage_pageable", &o_host_stage_pageable, [](int v) { return v == 0 || v == 1; }},
+  };
+  for (const Knob& k : knobs)
+    if (!std::strcmp(name, k.name)) {
+      if (!k.ok(value)) return SVBGPU_EINVAL;
+      k.cell->store(value, std::memory_order_relaxed);
+      return SVBGPU_OK;
+    }
   return SVBGPU_EINVAL;
 }
 
@@ -366,7 +369,7 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
   if (rc) return rc;
   rc = build_directory(variant, d_in, count, ws, S(stream));
   if (rc) return rc;
-  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
 }
 
 int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* ws, size_t ws_bytes,
@@ -392,7 +395,66 @@ int svbgpu_decode_run(int variant, unsigned flags, const uint8_t* d_in, uint32_t
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  return run_decode(variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+}
+
+}  // extern "C"
+
+// ---- svbgpu_decode_static: the decoder on scratch the library itself holds ------
+// Callers that cannot allocate (under graph capture, in a serving loop, in a
+// harness that forbids it) have no workspace to pass.  The workspace of this
+// entry point is a file-scope device array: kStaticScratchBytes on every GPU the
+// library runs on, held until the process ends.  In host code the array's name
+// is only a stand-in (passing it to a kernel would hand the kernel a host
+// address): the device address comes from hipGetSymbolAddress, once per device,
+// with that device current -- every GPU has its own copy at its own address.
+constexpr uint32_t kStaticMaxCount = SVBGPU_STATIC_MAX_COUNT;
+constexpr size_t kStaticScratchBytes = svb::ws_layout(kStaticMaxCount).total;
+static_assert(kStaticScratchBytes <= (4u << 20), "the static scratch is meant to stay modest");
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+void* g_static_ptr[64];  // device address of `scratch` per device ordinal, nullptr = not resolved yet
+std::mutex g_static_mu;
+// Device address of this device's copy of `scratch`.  Allocates nothing.
+int static_scratch(void** out) {
+  int d = 0;
+  HIP_TRY(hipGetDevice(&d));
+  if (d < 0 || d >= 64) return SVBGPU_ENODEVICE;
+  std::lock_guard<std::mutex> lk(g_static_mu);
+  if (!g_static_ptr[d]) {
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr || ((uintptr_t)ptr & 255u)) return SVBGPU_EWORKSPACE;
+    g_static_ptr[d] = ptr;
+  }
+  *out = g_static_ptr[d];
+  return SVBGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int svbgpu_decode_static(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
+                         uint32_t prev, uint64_t* d_consumed, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (count > kStaticMaxCount) return SVBGPU_ETOOBIG;
+  if (count == 0) {
+    if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  void* ws = nullptr;  // never the array's name: the address hipGetSymbolAddress gave for this device
+  int rc = static_scratch(&ws);
+  if (rc) return rc;
+  // Same kernels as svbgpu_decode.  Everything they read from the workspace is
+  // written first by this very call (directory by build_directory; header and
+  // look-back words cleared by run_decode before the look-back decoder), so what
+  // the previous call left behind does not matter.
+  rc = build_directory(variant, d_in, count, ws, S(stream));
+  if (rc) return rc;
+  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
 }
 
 int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,
@@ -408,8 +470,7 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t co
   if (rc) return rc;
   rc = clear_lookback(count, ws, S(stream));
   if (rc) return rc;
-  g_ws_bytes_hint = ws_bytes;
-  DISPATCH_VDZ(launch_encode, variant, flags, d_in, count, d_out, prev, ws, d_written, S(stream));
+  DISPATCH_VDZ(launch_encode, variant, flags, options(), d_in, count, d_out, prev, ws, ws_bytes, d_written, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
@@ -431,9 +492,9 @@ int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float
   std::memcpy(&bits, &scale, 4);
   const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
   if (variant == SVBGPU_1234)
-    launch_encode_qw<V1234, false, true, 4, true, 8>(in, count, d_out, bits, ws, d_written, S(stream));
+    launch_encode_qw<V1234, false, true, 4, true, 8>(options(), in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   else
-    launch_encode_qw<V0124, false, true, 4, true>(in, count, d_out, bits, ws, d_written, S(stream));
+    launch_encode_qw<V0124, false, true, 4, true>(options(), in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
@@ -454,7 +515,7 @@ int svbgpu_decode_dequantize(int variant, const uint8_t* d_in, float* d_out, uin
   uint32_t bits;
   std::memcpy(&bits, &scale, 4);
   const WsLayout L = ws_layout(count);
-  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, g_decode_per_cu);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, options().decode_per_cu);
   u32* out = reinterpret_cast<u32*>(d_out);
   u64* so = ws_at<u64>(ws, L.off_super_off);
   u32* wr = ws_at<u32>(ws, L.off_wt_rel);
@@ -543,11 +604,12 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   const WsLayout L = ws_layout(count);
   const u32 n_tiles8 = (u32)((L.n_wt + 31) / 32);  // 8 waves of 4 wave tiles per workgroup
   const u32 n_tiles16 = (u32)((L.n_wt + 63) / 64);
-  if (g_scan_waves == 16)
+  const int scan_waves = options().scan_waves;
+  if (scan_waves == 16)
     hipLaunchKernelGGL((k_running_sum<true, 16>), dim3(stream_grid(n_tiles16, 1)), dim3(1024), 0, S(stream), d_in,
                        reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles16, ws_hdr(ws),
                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
-  else if (g_scan_waves == 8)
+  else if (scan_waves == 8)
     hipLaunchKernelGGL((k_running_sum<true, 8>), dim3(stream_grid(n_tiles8, 2)), dim3(512), 0, S(stream), d_in,
                        reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles8, ws_hdr(ws),
                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
@@ -565,7 +627,7 @@ void launch_intersect(const uint8_t* d_in, uint32_t count, uint32_t prev, const 
                       uint32_t n_sorted, uint32_t* d_out, uint64_t* d_n_out, void* ws, uint64_t* d_consumed,
                       hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, g_decode_per_cu);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, options().decode_per_cu);
   u64* super_off = ws_at<u64>(ws, L.off_super_off);
   u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
   u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
@@ -617,7 +679,7 @@ int svbgpu_validate_batch(int variant, const uint8_t* d_bytes, const uint64_t* d
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_bytes || !d_byte_off || !d_lengths || !d_counts || !d_ok) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = batch_grid(nstreams);
+  const unsigned grid = batch_grid(options(), nstreams);
   if (variant == SVBGPU_1234)
     hipLaunchKernelGGL((k_validate_lists<V1234, u64, true>), dim3(grid), dim3(kBlock), 0, S(stream), d_bytes, d_byte_off,
                        d_counts, d_lengths, nstreams, d_ok);
@@ -636,7 +698,7 @@ int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t* d_values,
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_values || !d_value_off || !d_bytes || !d_byte_off || !d_counts || !d_sizes) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = batch_grid(nstreams);
+  const unsigned grid = batch_grid(options(), nstreams);
   DISPATCH_VDZ(launch_encode_batch, variant, flags, grid, d_values, d_value_off, d_bytes, d_byte_off,
                d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
@@ -650,7 +712,7 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, con
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_bytes || !d_byte_off || !d_values || !d_value_off || !d_counts) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = batch_grid(nstreams);
+  const unsigned grid = batch_grid(options(), nstreams);
   DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, d_bytes, d_byte_off, d_values, d_value_off,
                d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
@@ -725,17 +787,39 @@ void ctx_release(Ctx* c) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   g_pool.push_back(c);
 }
-// One host-pointer call drives the HIP runtime at a time.  The calls stay
-// re-entrant (own context, own stream, own buffers), but eight threads inside
-// the runtime at once ended in aborts from within it; every call ends with a
-// synchronisation anyway, so the device sees the same sequence of work.
-std::mutex g_host_api_mu;
+// Host-pointer calls are re-entrant: each has its own context (stream, buffers,
+// staging chunks).  With the "host_serialize" option on, one such call at a
+// time per DEVICE is inside the HIP runtime (a mutex per device ordinal; calls
+// on different devices never wait for each other).
+std::mutex g_host_api_mu[64];
+struct HostSerial {
+  std::mutex* mu = nullptr;
+  explicit HostSerial(const Options& o) {
+    int d = 0;
+    if (o.host_serialize && hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) {
+      mu = &g_host_api_mu[d];
+      mu->lock();
+    }
+  }
+  ~HostSerial() { if (mu) mu->unlock(); }
+  HostSerial(const HostSerial&) = delete;
+  HostSerial& operator=(const HostSerial&) = delete;
+};
 struct CtxGuard {
-  std::lock_guard<std::mutex> serial;
+  Options o;
+  HostSerial serial;
   Ctx* c;
-  CtxGuard() : serial(g_host_api_mu), c(ctx_acquire()) {}
+  CtxGuard() : o(options()), serial(o), c(ctx_acquire()) {}
   ~CtxGuard() { ctx_release(c); }
 };
+
+// The reference-named functions take device pointers in place, but work on the
+// context's own stream, which is ordered against nothing else: whatever the
+// caller still has in flight on the device (the kernel producing the input, a
+// memset of the output on any stream, the null stream included) must have ended
+// before that stream touches the buffers.  The calls are synchronous anyway
+// (they return a size), so a device-wide wait on entry costs nothing extra.
+void order_after_callers_work(std::initializer_list<const void*> ptrs);
 
 void grow(void*& p, size_t& cap, size_t need) {
   if (need <= cap) return;
@@ -780,8 +864,9 @@ bool is_pinned_host(const void* p) {
 // corruption and aborts inside the runtime; callers' buffers share pages.)
 // copy_in returns when the source has been read, copy_out when the destination
 // holds the data; both keep the order of the context's stream.
+bool g_stage_pageable() { return o_host_stage_pageable.load(std::memory_order_relaxed) != 0; }
 int copy_in(Ctx* c, void* d_dst, const void* h_src, size_t bytes) {
-  if (is_pinned_host(h_src)) {
+  if (is_pinned_host(h_src) || !g_stage_pageable()) {
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
     return SVBGPU_OK;
   }
@@ -799,7 +884,7 @@ int copy_in(Ctx* c, void* d_dst, const void* h_src, size_t bytes) {
   return SVBGPU_OK;
 }
 int copy_out(Ctx* c, void* h_dst, const void* d_src, size_t bytes) {
-  if (is_pinned_host(h_dst)) {
+  if (is_pinned_host(h_dst) || !g_stage_pageable()) {
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SVBGPU_OK;
@@ -831,6 +916,13 @@ uint64_t fetch_u64(Ctx* c, const uint64_t* d_word) {
   HIP_OR_DIE(hipStreamSynchronize(c->stream));
   return c->h_res[0];
 }
+void order_after_callers_work(std::initializer_list<const void*> ptrs) {
+  for (const void* p : ptrs)
+    if (is_device_ptr(p)) {
+      HIP_OR_DIE(hipDeviceSynchronize());
+      return;
+    }
+}
 void check_scan(Ctx* c) {
   HIP_OR_DIE(hipMemcpyAsync(c->h_res + 2, c->ws, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_OR_DIE(hipStreamSynchronize(c->stream));
@@ -842,6 +934,7 @@ size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t coun
   if (count == 0) return 0;
   CtxGuard g;
   Ctx* c = g.c;
+  order_after_callers_work({in, out});
   grow(c->ws, c->ws_cap, svbgpu_workspace_bytes(count));
   const uint32_t* d_in = in;
   if (!is_device_ptr(in)) {
@@ -868,11 +961,11 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
   if (count == 0) return 0;
   CtxGuard g;
   Ctx* c = g.c;
+  order_after_callers_work({in, out});
   grow(c->ws, c->ws_cap, svbgpu_workspace_bytes(count));
   const size_t keylen = ((size_t)count + 3) / 4;
   const uint8_t* d_in = in;
   int rc;
-  uint64_t total = 0;  // data bytes of the stream
   if (!is_device_ptr(in)) {
     // The stream's length is not known up front: stage the keys, let the
     // device sum them, then stage exactly the data bytes they promise.
@@ -880,7 +973,7 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
     COPY_OR_DIE(copy_in(c, c->a, in, keylen));
     rc = build_directory(variant, static_cast<const uint8_t*>(c->a), count, c->ws, c->stream);
     if (rc) die("decode (key scan)", rc);
-    total = fetch_u64(c, &ws_hdr(c->ws)->total_data);
+    const uint64_t total = fetch_u64(c, &ws_hdr(c->ws)->total_data);  // data bytes of the stream
     if (c->a_cap < keylen + total + 16) {
       grow(c->a, c->a_cap, keylen + total + 16);
       COPY_OR_DIE(copy_in(c, c->a, in, keylen + total));
@@ -891,7 +984,6 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
   } else {
     rc = build_directory(variant, d_in, count, c->ws, c->stream);
     if (rc) die("decode (key scan)", rc);
-    if (flags & SVBGPU_DELTA) total = fetch_u64(c, &ws_hdr(c->ws)->total_data);
   }
   const bool out_dev = is_device_ptr(out);
   uint32_t* d_out = out;
@@ -899,11 +991,11 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
     grow(c->b, c->b_cap, (size_t)count * 4);
     d_out = static_cast<uint32_t*>(c->b);
   }
-  rc = run_decode(variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream);
+  rc = run_decode(g.o, variant, flags, d_in, d_out, count, prev, c->ws, c->d_res, c->stream);
   if (rc) die("decode", rc);
   if (!out_dev) COPY_OR_DIE(copy_out(c, out, d_out, (size_t)count * 4));
   const uint64_t n = fetch_u64(c, c->d_res);
-  if ((flags & SVBGPU_DELTA) && g_delta_lookback) check_scan(c);  // only the look-back decoder (which clears it first) uses the error word
+  if ((flags & SVBGPU_DELTA) && g.o.delta_lookback) check_scan(c);  // only the look-back decoder (which clears it first) uses the error word
   return (size_t)n;
 }
 
@@ -911,6 +1003,7 @@ size_t size_any(int variant, const uint32_t* in, uint32_t count) {
   if (count == 0) return 0;
   CtxGuard g;
   Ctx* c = g.c;
+  order_after_callers_work({in});
   const uint32_t* d_in = in;
   if (!is_device_ptr(in)) {
     grow(c->a, c->a_cap, (size_t)count * 4);
@@ -929,6 +1022,7 @@ bool validate_any(int variant, const uint8_t* in, size_t in_length, uint32_t cou
   if (keylen > in_length) return false;
   CtxGuard g;
   Ctx* c = g.c;
+  order_after_callers_work({in});
   grow(c->ws, c->ws_cap, sizeof(WsHeader));
   const uint8_t* d_in = in;
   if (!is_device_ptr(in)) {
@@ -948,6 +1042,7 @@ void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
   if (n == 0) return;
   CtxGuard g;
   Ctx* c = g.c;
+  order_after_callers_work({in, out});
   const bool in_dev = is_device_ptr(in), out_dev = is_device_ptr(out);
   const void* d_in = in;
   void* d_out = out;
@@ -965,7 +1060,7 @@ void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
     // The device scan counts in 32 bits; a longer array (N is a size_t in the
     // reference, include/streamvbyte_zigzag.h:29) goes in pieces, each seeded with
     // the last value of the piece before it.
-    const size_t piece = g_zigzag_piece;
+    const size_t piece = (size_t)g.o.zigzag_piece;
     grow(c->ws, c->ws_cap, svbgpu_workspace_bytes((uint32_t)std::min(n, piece)));
     rc = SVBGPU_OK;
     for (size_t off = 0; off < n && !rc; off += piece) {

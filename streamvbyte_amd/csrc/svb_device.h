@@ -185,11 +185,11 @@ struct WsLayout {
   u64 n_wt, n_super, n_tiles;
   size_t off_super_off, off_wt_rel, off_super_sum, off_status, off_lb_group, off_wt_vsum, off_blk, off_bounds, total;
 };
-__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kLbWt = 16;  // wave tiles per look-back tile (16384 values)
 
-__host__ __device__ inline WsLayout ws_layout(u32 count) {
-  WsLayout L;
+__host__ __device__ constexpr WsLayout ws_layout(u32 count) {
+  WsLayout L{};
   u64 keylen = ((u64)count + 3) >> 2;
   L.n_wt = (keylen + kWtKeys - 1) / kWtKeys;
   L.n_super = (L.n_wt + kSuperWt - 1) / kSuperWt;

@@ -40,7 +40,9 @@ struct FrameSlots {
       grow(c[n]->a, c[n]->a_cap, a_bytes);
       grow(c[n]->b, c[n]->b_cap, b_bytes);
       grow(c[n]->ws, c[n]->ws_cap, svbgpu_workspace_bytes(max_count));
-      if (fill_u32(c[n]->ws, 0u, sizeof(WsHeader), c[n]->stream) != SVBGPU_OK) {  // error word starts clear
+      // the slot's sticky error word (d_res[7]) and the workspace header start clear
+      if (fill_u32(c[n]->ws, 0u, sizeof(WsHeader), c[n]->stream) != SVBGPU_OK ||
+          fill_u32(c[n]->d_res + 7, 0u, 8, c[n]->stream) != SVBGPU_OK) {
         ctx_release(c[n]);
         return SVBGPU_EHIP;
       }
@@ -75,8 +77,18 @@ struct FrameSlots {
     HIP_TRY(hipEventRecord(down[s], c[s]->stream));
     return SVBGPU_OK;
   }
-  int scan_status(int s) {  // error word of the slot's workspace (see svbgpu_check_status)
-    HIP_TRY(hipMemcpyAsync(c[s]->h_res + 2, c[s]->ws, 4, hipMemcpyDeviceToHost, c[s]->stream));
+  // Every look-back call of a frame begins by clearing its workspace header, error
+  // word included, so a give-up in frame i would be gone by frame i + kFrameSlots:
+  // right after a frame's kernels its error word is OR-ed into the slot's sticky
+  // word, which nothing clears until the call ends.
+  int keep_error(int s) {
+    hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(64), 0, c[s]->stream, reinterpret_cast<const u32*>(c[s]->ws),
+                       reinterpret_cast<u32*>(c[s]->d_res + 7));
+    HIP_TRY(hipGetLastError());
+    return SVBGPU_OK;
+  }
+  int scan_status(int s) {  // the slot's sticky error word
+    HIP_TRY(hipMemcpyAsync(c[s]->h_res + 2, c[s]->d_res + 7, 4, hipMemcpyDeviceToHost, c[s]->stream));
     HIP_TRY(hipStreamSynchronize(c[s]->stream));
     return reinterpret_cast<const uint32_t*>(c[s]->h_res + 2)[0] ? SVBGPU_ESCAN : SVBGPU_OK;
   }
@@ -174,7 +186,8 @@ int svbframe_encode_many(const uint32_t* in, size_t n, uint32_t frame_values, in
   if (out_capacity < svbframe_max_bytes_many(n, frame_values)) return SVBFRAME_ECAPACITY;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   const size_t nframes = (n + frame_values - 1) / frame_values;
-  std::lock_guard<std::mutex> serial(g_host_api_mu);
+  const Options opt = options();
+  HostSerial serial(opt);
   FrameSlots S;
   S.pinned_in = is_pinned_host(in);
   S.pinned_out = is_pinned_host(out);
@@ -194,6 +207,8 @@ int svbframe_encode_many(const uint32_t* in, size_t n, uint32_t frame_values, in
     if (r) return r;
     r = svbgpu_encode(variant, flags, static_cast<const uint32_t*>(c->a), cnt, static_cast<uint8_t*>(c->b),
                           prev, c->ws, c->ws_cap, c->d_res, c->stream);
+    if (r) return r;
+    r = S.keep_error((int)(i % kFrameSlots));
     if (r) return r;
     HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(S.ev[i % kFrameSlots], c->stream));
@@ -260,7 +275,8 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
   if (total > out_capacity) return SVBFRAME_ECAPACITY;
   if (fr.empty()) return SVBFRAME_OK;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  std::lock_guard<std::mutex> serial(g_host_api_mu);
+  const Options opt = options();
+  HostSerial serial(opt);
   FrameSlots S;
   S.pinned_in = is_pinned_host(frames);
   S.pinned_out = is_pinned_host(out);
@@ -288,9 +304,13 @@ int svbframe_decode_many(const uint8_t* frames, size_t bytes, uint32_t* out, siz
     if (reinterpret_cast<const uint32_t*>(c->h_res + 1)[0] != 1u) return SVBFRAME_EINVALID;
     int r = build_directory(f.inf.variant, static_cast<const uint8_t*>(c->a), f.inf.count, c->ws, c->stream);
     if (r) return r;
-    r = run_decode(f.inf.variant, f.inf.flags, static_cast<const uint8_t*>(c->a), static_cast<uint32_t*>(c->b),
+    r = run_decode(opt, f.inf.variant, f.inf.flags, static_cast<const uint8_t*>(c->a), static_cast<uint32_t*>(c->b),
                    f.inf.count, f.inf.prev, c->ws, nullptr, c->stream);
     if (r) return r;
+    if ((f.inf.flags & SVBGPU_DELTA) && opt.delta_lookback) {  // the only decoder that waits on other workgroups
+      r = S.keep_error((int)(i % kFrameSlots));
+      if (r) return r;
+    }
     return S.copy_down(i, out + f.voff, c->b, (size_t)f.inf.count * 4);
   };
   for (size_t i = 0; i < fr.size() + kFrameLag && !rc; ++i) {

@@ -156,7 +156,8 @@ int svbframe_encode_lists(const uint32_t* values, const uint64_t* list_start, si
   }
   if (out_capacity < need) return SVBFRAME_ECAPACITY;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  std::lock_guard<std::mutex> serial(g_host_api_mu);
+  const Options opt = options();
+  HostSerial serial(opt);
   FrameSlots S;
   S.pinned_in = values && is_pinned_host(values);
   S.pinned_out = is_pinned_host(out);
@@ -300,7 +301,8 @@ int svbframe_decode_lists(const uint8_t* frames, size_t bytes, uint32_t* values,
   fr.erase(std::remove_if(fr.begin(), fr.end(), [](const Ref& f) { return f.h.n_values == 0; }), fr.end());
   if (fr.empty()) return SVBFRAME_OK;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  std::lock_guard<std::mutex> serial(g_host_api_mu);
+  const Options opt = options();
+  HostSerial serial(opt);
   FrameSlots S;
   S.pinned_in = is_pinned_host(frames);
   S.pinned_out = is_pinned_host(values);

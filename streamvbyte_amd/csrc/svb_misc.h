@@ -12,6 +12,12 @@ __global__ void k_fill_u32(u32* __restrict__ p, u32 value, u64 n) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = value;
 }
 
+// Sticky error: OR the error word of a workspace header into *sticky (one
+// workgroup; ordered on the stream after the kernels whose give-ups it keeps).
+__global__ void k_keep_error(const u32* __restrict__ ws_error, u32* __restrict__ sticky) {
+  if (threadIdx.x == 0 && *ws_error) *sticky |= *ws_error;
+}
+
 // Block-wide sum of a 64-bit value, result valid in thread 0.
 __device__ __forceinline__ u64 block_sum64(u64 x, u64* s_tmp) {
   x = wave_sum64(x);
