@@ -46,6 +46,9 @@ extern "C" {
 #define SVBGPU_ESCAN (-5)      /* device scan did not converge (reported by
                                   svbgpu_check_status)                           */
 
+#define SVBGPU_ETOOBIG (-6)    /* count beyond SVBGPU_STATIC_MAX_COUNT
+                                  (svbgpu_decode_static only)                    */
+
 const char *svbgpu_strerror(int code);
 
 /* 1 when the current HIP device is a gfx950 the library can run on. */
@@ -114,6 +117,27 @@ int svbgpu_decode_plan(int variant, const uint8_t *d_in, uint32_t count, void *d
 int svbgpu_decode_run(int variant, unsigned flags, const uint8_t *d_in, uint32_t *d_out,
                       uint32_t count, uint32_t prev, void *d_workspace, size_t workspace_bytes,
                       uint64_t *d_consumed, void *stream);
+
+/* svbgpu_decode without a workspace argument, for callers that cannot
+ * allocate one: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  No counterpart in the reference (its decoder needs no
+ * scratch at all).  Same kernels, same results and same d_consumed as
+ * svbgpu_decode; the data-offset directory and the look-back words live in a
+ * static device array inside the library (about 2.9 MB per GPU, held until the
+ * process ends), so the call allocates nothing -- neither device nor host
+ * memory -- and only enqueues kernels on `stream`.
+ *   - count > SVBGPU_STATIC_MAX_COUNT is refused with SVBGPU_ETOOBIG (nothing
+ *     is enqueued); use svbgpu_decode with a workspace of your own.
+ *   - Every call on one GPU shares that GPU's array: calls must be ordered
+ *     (same stream, or events between streams); two that overlap race on the
+ *     directory and give wrong values.  Different GPUs never interfere.
+ *   - svbgpu_check_status does not apply (there is no workspace pointer to
+ *     give it); the look-back's bounded spin still guarantees termination.
+ *   - The first call on a device looks the array's address up
+ *     (hipGetSymbolAddress); make that call before starting a capture. */
+#define SVBGPU_STATIC_MAX_COUNT (1u << 28)
+int svbgpu_decode_static(int variant, unsigned flags, const uint8_t *d_in, uint32_t *d_out,
+                         uint32_t count, uint32_t prev, uint64_t *d_consumed, void *stream);
 
 /* Device-pointer form of streamvbyte_encode / _encode_0124 /
  * streamvbyte_delta_encode (reference include/streamvbyte.h:23,27,

@@ -36,6 +36,7 @@ SIGNATURES = {
     "svbgpu_decode": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]),
     "svbgpu_decode_plan": (C.c_int, [C.c_int, vp, C.c_uint32, vp, C.c_size_t, vp]),
     "svbgpu_decode_run": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]),
+    "svbgpu_decode_static": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svbgpu_encode": (C.c_int, [C.c_int, C.c_uint, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_size_t, vp, vp]),
     "svbgpu_quantize_encode": (C.c_int, [C.c_int, vp, C.c_uint32, C.c_float, vp, vp, C.c_size_t, vp, vp]),
     "svbgpu_decode_dequantize": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_float, C.c_int, vp, C.c_size_t, vp, vp]),
