@@ -94,11 +94,12 @@ struct Options {
   int batch_lists_per_wave;  // batched kernels: lists per wave of a launch, 0 = one grid that fills the device
   unsigned debug;        // timing-only ablations (wrong results!)
   int zigzag_piece;      // values per device scan of the host-pointer zigzag_delta_decode
+  int encode_pipeline;   // 1: k_encode_pipe (two half-size tiles in flight per workgroup), 0: k_encode
   int host_serialize;    // host-pointer calls: one at a time per device inside the runtime
   int host_stage_pageable;  // host-pointer calls: pageable caller memory moves through page-locked chunks
 };
 std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
-    o_encode_qw{4}, o_batch_lists_per_wave{8}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_serialize{1},
+    o_encode_qw{4}, o_encode_pipeline{1}, o_batch_lists_per_wave{8}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_serialize{1},
     o_host_stage_pageable{1};
 inline Options options() {
   Options o;
@@ -109,6 +110,7 @@ inline Options options() {
   o.delta_lookback = o_delta_lookback.load(rl);
   o.encode_waves = o_encode_waves.load(rl);
   o.encode_qw = o_encode_qw.load(rl);
+  o.encode_pipeline = o_encode_pipeline.load(rl);
   o.batch_lists_per_wave = o_batch_lists_per_wave.load(rl);
   o.debug = (unsigned)o_debug.load(rl);
   o.zigzag_piece = o_zigzag_piece.load(rl);
@@ -268,10 +270,34 @@ void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, ui
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, o.debug, stamps);
 }
+// The pipelined encoder: full tiles of NW waves x QW wave tiles by k_encode_pipe, the ragged last
+// tile by k_encode<.., FULL = false> of the same tile size on the same ticket and look-back words.
+template <int V, bool D, bool Z, int QW, bool QUANT = false, int NW = 8>
+void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
+                        size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
+  const unsigned full_tiles = (unsigned)(count / kTileInts);
+  const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
+  WsHeader* h = ws_hdr(ws);
+  const LbWords status{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+  // diagnostic stamps live behind the regular workspace when the caller over-allocated it
+  u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2) ? ws_at<u64>(ws, L.total) : nullptr;
+  if (full_tiles)
+    hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, QUANT, NW>), dim3(stream_grid(full_tiles, 2)), dim3(NW * 64), 0, st,
+                       d_in, count, full_tiles, d_out, prev, h, status, d_written, stamps);
+  if (ragged)
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
+                       d_out, prev, h, status, d_written, 0u, (u64*)nullptr);
+}
 template <int V, bool D, bool Z>
 void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                    size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
-  if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  // Differential coding keeps the larger tiles of k_encode: posting-list gaps are mostly one byte, the
+  // store phase is then short, and the pipelined kernel's twice as many tickets (one atomic on one word
+  // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
+  if (o.encode_pipeline && !D && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_waves == 8 && V == V1234)  // 0124 on small-valued input is faster with the smaller tile
     launch_encode_qw<V, D, Z, 4, false, V == V1234 ? 8 : kWaves>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
@@ -334,6 +360,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
+      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v == 0 || v == 1; }},
       {"host_serialize", &o_host_serialize, [](int v) { return v == 0 || v == 1; }},
       {"host_stage_pageable", &o_host_stage_pageable, [](int v) { return v == 0 || v == 1; }},
   };
@@ -491,10 +518,14 @@ int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float
   uint32_t bits;
   std::memcpy(&bits, &scale, 4);
   const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
-  if (variant == SVBGPU_1234)
-    launch_encode_qw<V1234, false, true, 4, true, 8>(options(), in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
+  const Options o = options();
+  if (o.encode_pipeline) {
+    if (variant == SVBGPU_1234) launch_encode_pipe<V1234, false, true, 2, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
+    else launch_encode_pipe<V0124, false, true, 2, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
+  } else if (variant == SVBGPU_1234)
+    launch_encode_qw<V1234, false, true, 4, true, 8>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   else
-    launch_encode_qw<V0124, false, true, 4, true>(options(), in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
+    launch_encode_qw<V0124, false, true, 4, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

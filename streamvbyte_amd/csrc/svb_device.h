@@ -92,6 +92,10 @@ __device__ __forceinline__ u32 wave_last(u32 x) { return (u32)__builtin_amdgcn_r
 __device__ __forceinline__ u32 wave_shift_up1(u32 x, u32 first) {
   return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138, 0xF, 0xF, false);  // wave_shr:1
 }
+// Value of the next lane; lane 63 receives `last`.
+__device__ __forceinline__ u32 wave_shift_down1(u32 x, u32 last) {
+  return (u32)__builtin_amdgcn_update_dpp((int)last, (int)x, 0x130, 0xF, 0xF, false);  // wave_shl:1
+}
 __device__ __forceinline__ u32 wave_sum(u32 x) { return wave_last(wave_scan_incl(x, 0)); }
 // 64-bit sum over the wavefront as three 32-bit DPP reductions of 26-bit pieces
 // (a chain of twelve ds_bpermute shuffles costs several hundred cycles).

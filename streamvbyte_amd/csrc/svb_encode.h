@@ -496,4 +496,184 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_encode_pipe: the encoder with the look-back taken off the critical path.
+//
+// k_encode runs a tile as load -> publish -> WAIT for the prefix -> store, and
+// the wait (a few memory round trips under load plus the slowest predecessor)
+// is over 40 % of a tile's life while its values sit in registers.  Here a
+// workgroup keeps TWO tiles of half the size in flight and loads, classifies
+// and publishes the NEXT one before it stores the current one:
+//
+//     T(b) | L(b) + R(a) | barrier | P(b) S(a) | T(c) | L(c) + R(b) | barrier | P(c) S(b) | ...
+//
+// (T ticket, L load + classify, P publish the tile's byte count, R resolve the
+// prefix, S assemble + store).  A tile is resolved a whole store + load phase
+// after it was published, when its predecessors' words have usually arrived:
+// wave 0 sends the polls right behind the loads of the next tile, so they
+// travel while that tile is classified, and one round answers.  Two barriers
+// per tile.  Between T(x) and P(x) the workgroup waits only for tiles with
+// smaller tickets (R of its previous tile), so by induction over the ticket
+// every ticketed tile is published: the look-back chain cannot deadlock.
+// Same registers as k_encode with tiles of twice the size (two tiles of QW wave
+// tiles per wave).  Handles only tiles that lie wholly inside the stream; the
+// ragged last tile is a launch of k_encode<.., QW, false, .., NW> on the same
+// look-back words.
+template <int V, bool DELTA, bool ZZ, int QW, bool QUANT = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
+    const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
+    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u64* __restrict__ stamps) {
+  __shared__ EncWaveLds s_lds[NW];
+  __shared__ u32 s_wave_tot[2][NW];
+  __shared__ u64 s_prefix;
+  __shared__ u32 s_tile;
+  // kT = 4: the tile words of the own group and of the 15 groups before it are read directly; group
+  // words are needed only for groups more than 240 tiles back, whose leaders have resolved long ago.
+  constexpr int kT = 4;
+
+  const int lane = lane_id(), wave = wave_id();
+  const u64 keylen = ((u64)count + 3) >> 2;
+  constexpr u64 kTileInts = (u64)NW * QW * kWtInts;
+  const u64 last_tile = keylen ? (keylen - 1) / ((u64)NW * QW * kWtKeys) : 0;
+  u8* data_out = out + keylen;
+  EncWaveLds& S = s_lds[wave];
+
+  // T: the barrier also ends the store phase before it (s_prefix, s_wave_tot and s_tile are free again)
+  auto draw = [&]() -> u32 {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(s_tile);
+  };
+  // wave 0: prefix of `tile` (whose byte count is tile_tot) into s_prefix; `first` = polls already sent
+  auto resolve = [&](u32 tile, u32 tile_tot, const LbState<kT>* first) {
+    u32 rounds = 0;
+    const u64 excl = lb2_resolve<kT>(lb, tile, tile_tot, lane, &hdr->error, &rounds, first);
+    if (lane == 0) {
+      s_prefix = excl;
+      if (tile == last_tile && written) *written = keylen + excl + tile_tot;
+      if (stamps) {  // diagnostic build only: wall-clock stamps per tile, 100 MHz
+        stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();
+        stamps[5 * (u64)tile + 4] = rounds;
+      }
+    }
+  };
+  // L (+ R of the tile before): values of `tile` into x, their keys into kq, the waves' byte counts
+  // into s_wave_tot[buf]; wave 0 resolves tile_res meanwhile (0xFFFFFFFF: none).
+  auto load = [&](u32 tile, int buf, uint4 (&x)[QW][4], u32 (&kq)[QW], u32 tile_res, u32 tot_res) {
+    if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 0] = __builtin_amdgcn_s_memrealtime();
+    const u64 wave_first = (u64)tile * kTileInts + (u64)wave * QW * kWtInts;
+    const uint4* src = reinterpret_cast<const uint4*>(in + wave_first);
+#pragma unroll
+    for (int q = 0; q < QW; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[q][j] = src[(u32)lane + (u32)(q * 256 + j * 64)];
+    LbState<kT> polls;
+    const bool resolving = wave == 0 && tile_res != 0xFFFFFFFFu;
+    if (resolving) polls = lb2_begin<kT>(lb, tile_res, lane);
+    if (QUANT) {
+      const float scale = __uint_as_float(prev);
+      auto q1 = [scale](u32 bits) -> u32 { return (u32)(int)rintf(__fmul_rn(__uint_as_float(bits), scale)); };
+#pragma unroll
+      for (int q = 0; q < QW; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint4& c = x[q][j];
+          c = make_uint4(q1(c.x), q1(c.y), q1(c.z), q1(c.w));
+        }
+    }
+    if (DELTA) {
+      u32 carry = prev;
+      if (wave_first > 0) carry = in[wave_first - 1];
+#pragma unroll
+      for (int q = 0; q < QW; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint4 c = x[q][j];
+          const u32 pv = wave_shift_up1(c.w, carry);
+          carry = wave_last(c.w);
+          x[q][j] = make_uint4(c.x - pv, c.y - c.x, c.z - c.y, c.w - c.z);
+        }
+    }
+    u32 lane_tot = 0;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4& c = x[q][j];
+        if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
+      }
+      u32 k4 = classify_key<V>(x[q][0]) | (classify_key<V>(x[q][1]) << 8) | (classify_key<V>(x[q][2]) << 16) |
+               (classify_key<V>(x[q][3]) << 24);
+      asm volatile("" : "+v"(k4));  // the four keys stay in ONE register
+      kq[q] = k4;
+      lane_tot += word_len<V>(k4, 16u);
+    }
+    const u32 wave_tot = wave_sum(lane_tot);
+    if (lane == 0) s_wave_tot[buf][wave] = wave_tot;
+    if (resolving) resolve(tile_res, tot_res, &polls);
+  };
+  // P (wave 0): the tile's byte count becomes visible to later tiles.  Returns it (valid in wave 0).
+  auto publish = [&](u32 tile, int buf) -> u32 {
+    u32 tile_tot = 0;
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[buf][w];
+      lb2_publish(lb, tile, tile_tot, lane);
+      if (stamps && lane == 0) stamps[5 * (u64)tile + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    return tile_tot;
+  };
+  // S: assemble and store the wave tiles of `tile`, whose prefix is in s_prefix.
+  auto store = [&](u32 tile, int buf, uint4 (&x)[QW][4], u32 (&kq)[QW]) {
+    u64 doff = s_prefix;
+    for (int w = 0; w < wave; ++w) doff += s_wave_tot[buf][w];
+    const u64 wave_first = (u64)tile * kTileInts + (u64)wave * QW * kWtInts;
+#pragma unroll 1
+    for (int q = 0; q < QW; ++q) {
+      const u64 wt_first = wave_first + (u64)q * kWtInts;
+      const u32 lens4 = key_lens4<V>(kq[0], 16u);
+      u32 gq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gq[j] = ((kq[0] >> (8 * j)) & 0xFFu) | (((lens4 >> (8 * j)) & 0xFFu) << 24);
+      doff += encode_wavetile<V, true>(x[0], gq, kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
+#pragma unroll
+      for (int r = 0; r + 1 < QW; ++r) {
+        kq[r] = kq[r + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[r][j] = x[r + 1][j];
+      }
+    }
+    if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 3] = __builtin_amdgcn_s_memrealtime();
+  };
+
+  uint4 xa[QW][4], xb[QW][4];
+  u32 kqa[QW], kqb[QW];
+  u32 tile_a = draw();
+  if (tile_a >= n_tiles) return;
+  load(tile_a, 0, xa, kqa, 0xFFFFFFFFu, 0u);
+  __syncthreads();
+  u32 tot_a = publish(tile_a, 0);
+  int buf = 0;
+  for (;;) {
+    const u32 tile_b = draw();
+    const bool more = tile_b < n_tiles;  // workgroup-uniform
+    if (more) load(tile_b, buf ^ 1, xb, kqb, tile_a, tot_a);
+    else if (wave == 0) resolve(tile_a, tot_a, nullptr);
+    __syncthreads();
+    u32 tot_b = 0;
+    if (more) tot_b = publish(tile_b, buf ^ 1);
+    store(tile_a, buf, xa, kqa);
+    if (!more) break;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      kqa[q] = kqb[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xa[q][j] = xb[q][j];
+    }
+    tile_a = tile_b;
+    tot_a = tot_b;
+    buf ^= 1;
+  }
+}
+
 }  // namespace svb

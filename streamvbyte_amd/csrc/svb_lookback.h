@@ -43,18 +43,52 @@ struct LbWords {
 };
 // kT = tile words polled per lane: the window of tiles read one by one covers
 // the tile's own group and the 4 kT - 1 groups before it.
+// The two halves of a look-back, for kernels that do other work between
+// publishing a tile's aggregate and needing its prefix (by then the
+// predecessors' words have usually arrived and one poll round answers):
+//   lb2_publish   the tile's aggregate becomes visible to later tiles
+//   lb2_resolve   poll until the exclusive prefix of the tile is known
+// lb2_exclusive_prefix is one after the other.
+__device__ __forceinline__ void lb2_publish(const LbWords& L, u32 tile, u64 my_agg, int lane) {
+  if (lane == 0) __hip_atomic_store(L.tile + tile, kLbAgg | my_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// What the first poll round of a look-back read (lb2_begin): words not yet
+// published are 0 and are polled again by lb2_resolve.
+template <int kT>
+struct LbState {
+  u64 tw[kT];
+  u64 gw;
+};
+// Sends the first round of polls of `tile`'s look-back and returns without
+// looking at the answers, so that they travel while the caller does other work.
 template <int kT = 2>
-__device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, u64 my_agg, int lane,
-                                                    u32* err, u32* rounds_out = nullptr) {
+__device__ __forceinline__ LbState<kT> lb2_begin(const LbWords& L, u32 tile, int lane) {
+  constexpr u32 kDirect = 4 * kT - 1;
+  const u32 k = tile >> 4;
+  const u32 g0 = k > kDirect ? k - kDirect : 0u;
+  const int t0 = 16 * (int)g0;
+  LbState<kT> st;
+#pragma unroll
+  for (int i = 0; i < kT; ++i) {
+    const int idx = (int)tile - 1 - lane - 64 * i;
+    st.tw[i] = idx >= t0 ? __hip_atomic_load(L.tile + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  }
+  const int gidx = (int)g0 - 1 - lane;
+  st.gw = gidx >= 0 ? __hip_atomic_load(L.group + gidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  return st;
+}
+template <int kT = 2>
+__device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_agg, int lane, u32* err,
+                                           u32* rounds_out = nullptr, const LbState<kT>* first = nullptr) {
   constexpr u32 kDirect = 4 * kT - 1;
   const u32 k = tile >> 4;
   const u32 g0 = k > kDirect ? k - kDirect : 0u;  // first group of the tile window
   const int t0 = 16 * (int)g0;  // tile and group indices fit 32 bits (at most 2^20 tiles)
-  if (lane == 0) __hip_atomic_store(L.tile + tile, kLbAgg | my_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool leader = (tile & 15u) == 15u;
   u64 tw[kT], gw = 0, mine = 0;
 #pragma unroll
-  for (int i = 0; i < kT; ++i) tw[i] = 0;
+  for (int i = 0; i < kT; ++i) tw[i] = first ? first->tw[i] : 0ull;
+  if (first) gw = first->gw;
   int gbase = (int)g0 - 1;  // nearest group not yet summed
   bool tile_done = false, group_done = false, agg_out = false;
   u32 spins = 0, rounds = 0, tile_round = 0, group_round = 0;  // the *_round values feed diagnostics only
@@ -125,6 +159,12 @@ __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, 
     __hip_atomic_store(L.group + k, kLbPfx | (prefix + my_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (rounds_out) *rounds_out = rounds | (tile_round << 8) | (group_round << 16);
   return prefix;
+}
+template <int kT = 2>
+__device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, u64 my_agg, int lane,
+                                                    u32* err, u32* rounds_out = nullptr) {
+  lb2_publish(L, tile, my_agg, lane);
+  return lb2_resolve<kT>(L, tile, my_agg, lane, err, rounds_out);
 }
 
 }  // namespace svb

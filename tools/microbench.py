@@ -70,9 +70,20 @@ if want("ablate"):
     ops["encode_nopass2"] = (dbg_with(2, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_idle11us"] = (dbg_with(5, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_neither"] = (dbg_with(3, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+def opt_with(name, value, default, f):
+    def g():
+        codec.lib.svbgpu_set_option(name, value)
+        f()
+        codec.lib.svbgpu_set_option(name, default)
+    return g
+
+
 if want("encode"):
+    ops["encode"] = (lambda: codec.encode(values, out=enc_out), (4.25 + dbar) * n)
+    ops["encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+if want("encode_qw"):
     for qw in (1, 2, 4):
-        ops[f"encode_qw{qw}"] = (enc_with(qw, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+        ops[f"encode_qw{qw}"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(qw, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
 if want("delta"):
     g = torch.Generator(device=dev); g.manual_seed(7)
     post = torch.cumsum(torch.randint(0, 32, (n,), generator=g, device=dev, dtype=torch.int64), 0)
@@ -81,6 +92,7 @@ if want("delta"):
     s3 = s3.clone()
     d3 = (int(z3.item()) - keylen) / n
     ops["delta_encode"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
+    ops["delta_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
     ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
 
     def dd_twopass():
@@ -88,6 +100,8 @@ if want("delta"):
         codec.decode(s3, n, out=out, flags=svb.DELTA)
         codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
     ops["delta_decode_twopass"] = (dd_twopass, (4.25 + d3) * n)
+    ops["delta_encode_mixed"] = (lambda: codec.encode(values, out=enc_out, flags=svb.DELTA), (4.25 + dbar) * n)
+    ops["delta_encode_mixed_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(values, out=enc_out, flags=svb.DELTA)), (4.25 + dbar) * n)
     sm, zm = codec.encode(values, flags=svb.DELTA)
     sm = sm.clone()
     ops["delta_decode_mixed"] = (lambda: codec.decode(sm, n, out=out, flags=svb.DELTA), (int(zm.item()) + 4.0 * n))
@@ -106,6 +120,7 @@ if want("zz"):
     d4 = (int(z4.item()) - (n4 + 3) // 4) / n4
     o4 = out[:n4]
     ops["zz0124_encode"] = (lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
+    ops["zz0124_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
     ops["zz0124_decode"] = (lambda: codec.decode(s4, n4, out=o4, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
 if want("misc"):
     ops["validate"] = (lambda: codec.validate(stream, size, n), 0.25 * n)
