@@ -17,6 +17,7 @@
 #include "../../include/streamvbyte_gpu.h"
 #include "../../include/streamvbyte_zigzag.h"
 #include "../../include/streamvbytedelta.h"
+#include "svb_cpu.h"
 #include "svb_decode.h"
 #include "svb_delta.h"
 #include "svb_encode.h"
@@ -91,15 +92,18 @@ struct Options {
   int delta_lookback;    // 1: single-pass look-back differential decoder, 0: two streaming passes
   int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8)
   int encode_qw;         // wave tiles per wave in k_encode (1, 2 or 4)
-  int batch_lists_per_wave;  // batched kernels: lists per wave of a launch, 0 = one grid that fills the device
+  int batch_lists_per_wave;  // row/wave batched kernels: lists per wave of a launch, 0 = one grid that fills the device
+  int batch_chunk;       // batched calls: -1 chunked kernels, streams per wavefront chosen from the batch size;
+                         // 1..64 chunked kernels with that many; 0 the row + wave kernel pair
   unsigned debug;        // timing-only ablations (wrong results!)
   int zigzag_piece;      // values per device scan of the host-pointer zigzag_delta_decode
   int encode_pipeline;   // 1: k_encode_pipe (two half-size tiles in flight per workgroup), 0: k_encode
+  int host_cpu_cutoff;   // host-pointer calls on fewer values than this run on the host codec (svb_cpu.h)
   int host_serialize;    // host-pointer calls: one at a time per device inside the runtime
   int host_stage_pageable;  // host-pointer calls: pageable caller memory moves through page-locked chunks
 };
 std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
-    o_encode_qw{4}, o_encode_pipeline{1}, o_batch_lists_per_wave{8}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_serialize{1},
+    o_encode_qw{4}, o_encode_pipeline{1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
     o_host_stage_pageable{1};
 inline Options options() {
   Options o;
@@ -112,8 +116,10 @@ inline Options options() {
   o.encode_qw = o_encode_qw.load(rl);
   o.encode_pipeline = o_encode_pipeline.load(rl);
   o.batch_lists_per_wave = o_batch_lists_per_wave.load(rl);
+  o.batch_chunk = o_batch_chunk.load(rl);
   o.debug = (unsigned)o_debug.load(rl);
   o.zigzag_piece = o_zigzag_piece.load(rl);
+  o.host_cpu_cutoff = o_host_cpu_cutoff.load(rl);
   o.host_serialize = o_host_serialize.load(rl);
   o.host_stage_pageable = o_host_stage_pageable.load(rl);
   return o;
@@ -244,6 +250,16 @@ int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_i
 // the device and the hardware hands them out as earlier ones finish.  Lists differ in length by orders of
 // magnitude; lists strided over a grid that just fills the device left some waves with 1.3x the average
 // work.  0 = such a persistent grid.  See svbgpu_set_option.
+// Streams of the batch per wavefront in the long-stream blocks of the chunked batch kernels: `most` when
+// the batch is large enough to give every CU some 32 wavefronts that way (measured best on a million
+// posting lists: 32 for the decoder, 8 for the encoder), fewer for smaller batches so that the device still
+// fills.
+inline unsigned batch_chunk(const Options& o, uint32_t nstreams, unsigned most) {
+  if (o.batch_chunk >= 0) return (unsigned)o.batch_chunk;
+  const unsigned long long want_waves = (unsigned long long)(dev_info().cus ? dev_info().cus : 256) * 32;
+  const unsigned long long k = nstreams / want_waves;
+  return (unsigned)(k < 1 ? 1 : (k > most ? most : k));
+}
 inline unsigned batch_grid(const Options& o, uint32_t nstreams) {
   const unsigned long long blocks = ((unsigned long long)nstreams + kWaves - 1) / kWaves;
   const unsigned fill = stream_grid(blocks, 8);
@@ -356,11 +372,13 @@ int svbgpu_set_option(const char* name, int value) {
       {"decode_shortcut", &o_decode_shortcut, [](int v) { return v == 0 || v == 1; }},
       {"delta_decode_lookback", &o_delta_lookback, [](int v) { return v == 0 || v == 1; }},
       {"batch_lists_per_wave", &o_batch_lists_per_wave, [](int v) { return v >= 0; }},
+      {"batch_chunk", &o_batch_chunk, [](int v) { return v >= -1 && v <= 64; }},
       {"decode_grid_per_cu", &o_decode_per_cu, [](int v) { return v >= 0; }},
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
       {"encode_pipeline", &o_encode_pipeline, [](int v) { return v == 0 || v == 1; }},
+      {"host_cpu_cutoff", &o_host_cpu_cutoff, [](int v) { return v >= 0; }},
       {"host_serialize", &o_host_serialize, [](int v) { return v == 0 || v == 1; }},
       {"host_stage_pageable", &o_host_stage_pageable, [](int v) { return v == 0 || v == 1; }},
   };
@@ -729,8 +747,9 @@ int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t* d_values,
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_values || !d_value_off || !d_bytes || !d_byte_off || !d_counts || !d_sizes) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = batch_grid(options(), nstreams);
-  DISPATCH_VDZ(launch_encode_batch, variant, flags, grid, d_values, d_value_off, d_bytes, d_byte_off,
+  const Options o = options();
+  const unsigned grid = batch_grid(o, nstreams);
+  DISPATCH_VDZ(launch_encode_batch, variant, flags, grid, batch_chunk(o, nstreams, 8), d_values, d_value_off, d_bytes, d_byte_off,
                d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
@@ -743,8 +762,9 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, con
   if (nstreams == 0) return SVBGPU_OK;
   if (!d_bytes || !d_byte_off || !d_values || !d_value_off || !d_counts) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
-  const unsigned grid = batch_grid(options(), nstreams);
-  DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, d_bytes, d_byte_off, d_values, d_value_off,
+  const Options o = options();
+  const unsigned grid = batch_grid(o, nstreams);
+  DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, batch_chunk(o, nstreams, 32), d_bytes, d_byte_off, d_values, d_value_off,
                d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
@@ -888,6 +908,20 @@ bool is_pinned_host(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
+// Where a reference-named call runs.  Device pointers always go to the kernels
+// (in place).  Host pointers go to the kernels too, staged over PCIe, unless the
+// call is small -- below "host_cpu_cutoff" values the two PCIe crossings and the
+// launch latency (~100 us) cost more than the host codec takes -- or the process
+// has no gfx950 device, in which case the host codec is all there is (the
+// reference never fails: include/streamvbyte.h:64 there).  The svbgpu_* API
+// never takes this path.
+bool run_on_host(size_t count, std::initializer_list<const void*> ptrs) {
+  for (const void* p : ptrs)
+    if (is_device_ptr(p)) return false;
+  if (!dev_info().ok) return true;
+  return count < (size_t)o_host_cpu_cutoff.load(std::memory_order_relaxed);
+}
+
 // Host <-> device copies of the host-pointer API.  HIP never sees a pageable
 // caller pointer: such memory moves through the context's own page-locked
 // chunks with plain memcpy on this thread, two chunks in flight.  (Handing
@@ -963,6 +997,7 @@ void check_scan(Ctx* c) {
 size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t count, uint8_t* out,
                   uint32_t prev) {
   if (count == 0) return 0;
+  if (run_on_host(count, {in, out})) return svbcpu::encode_any(variant, flags & SVBGPU_DELTA, in, count, out, prev);
   CtxGuard g;
   Ctx* c = g.c;
   order_after_callers_work({in, out});
@@ -990,6 +1025,7 @@ size_t encode_any(int variant, unsigned flags, const uint32_t* in, uint32_t coun
 size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out, uint32_t count,
                   uint32_t prev) {
   if (count == 0) return 0;
+  if (run_on_host(count, {in, out})) return svbcpu::decode_any(variant, flags & SVBGPU_DELTA, in, out, count, prev);
   CtxGuard g;
   Ctx* c = g.c;
   order_after_callers_work({in, out});
@@ -1032,6 +1068,8 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
 
 size_t size_any(int variant, const uint32_t* in, uint32_t count) {
   if (count == 0) return 0;
+  if (run_on_host(count, {in}))
+    return variant == SVBGPU_1234 ? svbcpu::compressedbytes<svbcpu::k1234>(in, count) : svbcpu::compressedbytes<svbcpu::k0124>(in, count);
   CtxGuard g;
   Ctx* c = g.c;
   order_after_callers_work({in});
@@ -1051,6 +1089,8 @@ bool validate_any(int variant, const uint8_t* in, size_t in_length, uint32_t cou
   if (in_length == 0 || count == 0) return in_length == (size_t)count;
   const size_t keylen = ((size_t)count + 3) / 4;
   if (keylen > in_length) return false;
+  if (run_on_host(count, {in}))
+    return variant == SVBGPU_1234 ? svbcpu::validate<svbcpu::k1234>(in, in_length, count) : svbcpu::validate<svbcpu::k0124>(in, in_length, count);
   CtxGuard g;
   Ctx* c = g.c;
   order_after_callers_work({in});
@@ -1071,6 +1111,7 @@ bool validate_any(int variant, const uint8_t* in, size_t in_length, uint32_t cou
 
 void zigzag_any(int mode, const void* in, void* out, size_t n, int32_t prev) {
   if (n == 0) return;
+  if (run_on_host(n, {in, out})) return svbcpu::zigzag(mode, in, out, n, prev);
   CtxGuard g;
   Ctx* c = g.c;
   order_after_callers_work({in, out});

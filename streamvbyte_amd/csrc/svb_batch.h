@@ -224,11 +224,315 @@ __global__ __launch_bounds__(kBlock) void k_encode_batch(
   }
 }
 
+
+// ===========================================================================
+// Chunked batch kernels: a wavefront takes K consecutive streams (K <= 64), lane
+// i holds the directory entry of stream i of the chunk (three coalesced loads
+// for up to 64 streams instead of dependent scalar loads per stream), and the
+// chunk is worked off in two parts:
+//
+//  * FLAT: all streams of up to kFlatMax values together, one GROUP per lane
+//    and step whatever stream it belongs to.  The groups of the chunk's short
+//    streams are numbered consecutively ("slots"); a step covers 64 slots.  A
+//    64-bit mask of the slots where a stream starts gives every lane its stream
+//    (population count below the lane), a SEGMENTED scan over the lanes (key =
+//    the stream) turns group lengths into data offsets and, for differential
+//    coding, group sums into running values; a stream cut by a step's end is
+//    carried into the next step.  Lanes are full whatever the length mix:
+//    streams of 3 values and of 200 values cost the same per group.
+//  * LONG: streams beyond kFlatMax values one after the other, the whole
+//    wavefront on one wave tile at a time as in the single-stream kernels, the
+//    next wave tile's keys requested before the current one is decoded.
+//
+// No workspace, no pass over the whole directory per length class, one launch.
+// Per-stream results equal the single-stream calls (reference
+// src/streamvbyte_decode.c:64-87, src/streamvbyte_encode.c:113-137 list by list).
+constexpr u32 kFlatMax = 256;  // values; such a stream has at most 64 groups
+
+// Directory entry of a short stream, compacted to the front of the wave's LDS.
+struct __align__(16) FlatEnt {
+  u64 boff, voff;
+  u32 cnt, first_slot, prev, sid;
+};
+static_assert(sizeof(FlatEnt) == 32 && 64 * sizeof(FlatEnt) <= kWtDataMax, "entries alias the wave's data image");
+
+// What a lane needs to know about its slot in one step of the flat part.
+struct FlatSlot {
+  FlatEnt e;    // the slot's stream
+  u32 idx;      // index of that stream among the chunk's short streams (the segment key)
+  u32 gi;       // group index inside the stream
+  bool have;    // the slot exists
+};
+// Compacts the short streams' entries into `ent` and returns the number of slots.
+__device__ __forceinline__ u32 flat_setup(bool is_short, u32 cnt, u64 boff, u64 voff, u32 prev, u32 sid, int lane,
+                                          FlatEnt* ent, u32& n_short, u32& my_first) {
+  const u32 ng = is_short ? (cnt + 3u) >> 2 : 0u;
+  const u32 incl = wave_scan_incl(ng, lane);
+  const u64 smask = __ballot(is_short);
+  const u32 rank = (u32)__popcll(smask & ((1ull << lane) - 1ull));
+  if (is_short) {
+    FlatEnt e;
+    e.boff = boff; e.voff = voff; e.cnt = cnt; e.first_slot = incl - ng; e.prev = prev; e.sid = sid;
+    ent[rank] = e;
+  }
+  n_short = (u32)__popcll(smask);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  my_first = (u32)lane < n_short ? ent[lane].first_slot : 0xFFFFFFFFu;
+  return wave_last(incl);
+}
+__device__ __forceinline__ FlatSlot flat_slot(u32 base, u32 n_slots, u32 n_short, u32 my_first, int lane,
+                                              const FlatEnt* ent) {
+  // bit h of the mask: a stream starts at slot base + h
+  const u32 h = my_first - base;
+  const bool head_here = my_first != 0xFFFFFFFFu && my_first >= base && h < 64u;
+  const u32 m_lo = wave_or(head_here && h < 32u ? 1u << h : 0u);
+  const u32 m_hi = wave_or(head_here && h >= 32u ? 1u << (h - 32u) : 0u);
+  const u64 heads = ((u64)m_hi << 32) | m_lo;
+  const u32 before = (u32)__popcll(__ballot(my_first < base));  // streams that started in earlier steps
+  FlatSlot s;
+  s.have = base + lane < n_slots;
+  const u64 upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  u32 idx = before + (u32)__popcll(heads & upto) - 1u;
+  s.idx = min(idx, n_short - 1u);  // slots past the end borrow the last stream's entry and do nothing
+  s.e = ent[s.idx];
+  s.gi = base + lane - s.e.first_slot;
+  return s;
+}
+
+// Blocks [0, n_long_blocks) work off the LONG streams, K_long of the batch's streams per wavefront;
+// the blocks behind them the FLAT part, 64 streams per wavefront (few streams per wavefront keep the
+// long-running wavefronts similar in length and the launch's tail short; many keep the flat steps full).
+template <int V, bool DELTA, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_decode_batch2(
+    const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
+    const u64* __restrict__ value_off, const u32* __restrict__ counts,
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks) {
+  __shared__ WaveLds s_lds[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  WaveLds& S = s_lds[wave];
+  const bool flat_role = blockIdx.x >= n_long_blocks;
+  const u32 K = flat_role ? 64u : K_long;
+  const u64 s0 = ((u64)(flat_role ? blockIdx.x - n_long_blocks : blockIdx.x) * kWaves + wave) * K;
+  if (s0 >= nstreams) return;  // wave-uniform; no workgroup barrier below
+  const bool valid = (u32)lane < K && s0 + lane < nstreams;
+  const u32 sid = (u32)(s0 + lane);
+  u32 cnt = 0, prev = 0;
+  u64 boff = 0, voff = 0;
+  if (valid) {
+    cnt = counts[sid];
+    boff = byte_off[sid];
+    voff = value_off[sid];
+    if (DELTA && prevs) prev = prevs[sid];
+  }
+
+  if (flat_role) {
+    if (valid && cnt == 0 && sizes) sizes[sid] = 0;
+    const bool is_short = valid && cnt > 0 && cnt <= kFlatMax;
+    FlatEnt* ent = reinterpret_cast<FlatEnt*>(S.data);
+    u32 n_short, my_first;
+    const u32 n_slots = flat_setup(is_short, cnt, boff, voff, prev, sid, lane, ent, n_short, my_first);
+    u32 carry_idx = 0xFFFFFFFFu, carry_doff = 0, carry_val = 0;  // wave-uniform: the stream cut by the last step's end
+    for (u32 base = 0; base < n_slots; base += 64) {
+      const FlatSlot f = flat_slot(base, n_slots, n_short, my_first, lane, ent);
+      const u8* in = bytes + f.e.boff;
+      const u32 keylen = (f.e.cnt + 3u) >> 2;
+      u32 key = f.have ? in[f.gi] : 0u;
+      const u32 nv = f.have ? min(4u, f.e.cnt - 4u * f.gi) : 0u;
+      key &= nv >= 4u ? 0xFFu : ((1u << (2u * nv)) - 1u);
+      const u32 L = group_len<V>(key, nv);
+      const u32 incl = seg_add_scan(f.idx, L) + (f.idx == carry_idx ? carry_doff : 0u);
+      uint4 d = make_uint4(0, 0, 0, 0);
+      if (f.have) d = ld_u128(in + keylen + (incl - L));
+      uint4 c = values_of_group<V, ZZ>(d, key, nv);
+      if (DELTA) {
+        c.y += c.x; c.z += c.y; c.w += c.z;
+        const u32 si = seg_add_scan(f.idx, c.w) + (f.idx == carry_idx ? carry_val : f.e.prev);
+        const u32 ex = si - c.w;
+        c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+      }
+      if (f.have) {
+        store_group(values + f.e.voff, 4ull * f.gi, f.e.cnt, c);
+        if (sizes && f.gi == keylen - 1u) sizes[f.e.sid] = (u64)keylen + incl;
+      }
+      carry_idx = (u32)__builtin_amdgcn_readlane((int)f.idx, 63);
+      carry_doff = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+      if (DELTA) carry_val = (u32)__builtin_amdgcn_readlane((int)c.w, 63);
+    }
+    return;
+  }
+
+  // ---- long streams, one after the other, the whole wavefront on a wave tile at a time ----
+  u64 todo = __ballot(valid && cnt > kFlatMax);
+  while (todo) {
+    const int src = (int)__builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const u32 count = (u32)__builtin_amdgcn_readlane((int)cnt, src);
+    const u64 lboff = ((u64)(u32)__builtin_amdgcn_readlane((int)(boff >> 32), src) << 32) |
+                      (u32)__builtin_amdgcn_readlane((int)boff, src);
+    const u64 lvoff = ((u64)(u32)__builtin_amdgcn_readlane((int)(voff >> 32), src) << 32) |
+                      (u32)__builtin_amdgcn_readlane((int)voff, src);
+    u32 run = (u32)__builtin_amdgcn_readlane((int)prev, src);
+    const u8* in = bytes + lboff;
+    u32* out = values + lvoff;
+    const u64 keylen = ((u64)count + 3) >> 2;
+    const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+    u64 doff = 0;
+    auto load_keys = [&](u32 wt) -> u32 {
+      const u64 koff = (u64)wt * kWtKeys + 4 * lane;
+      return koff < keylen ? ld_u32(in + koff) : 0u;  // may overrun the keys by < 4 B: data or padding
+    };
+    u32 w_next = load_keys(0);
+    for (u32 wt = 0; wt < n_wt; ++wt) {
+      const u32 w = w_next;
+      if (wt + 1 < n_wt) w_next = load_keys(wt + 1);  // the next wave tile's keys travel meanwhile
+      const u64 int0 = (u64)wt * kWtInts;
+      const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
+      uint4 v[4];
+      doff += decode_wavetile<V, ZZ>(w, nints, in + keylen + doff, lane, S, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4 c = v[j];
+        if (DELTA) {
+          c.y += c.x; c.z += c.y; c.w += c.z;
+          const u32 incl = wave_scan_incl(c.w, lane);
+          const u32 ex = incl - c.w + run;
+          run += wave_last(incl);
+          c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+        }
+        store_group(out, int0 + 4u * (j * 64 + lane), count, c);
+      }
+    }
+    if (sizes && lane == 0) sizes[s0 + src] = keylen + doff;
+  }
+}
+
+template <int V, bool DELTA, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_encode_batch2(
+    const u32* __restrict__ values, const u64* __restrict__ value_off, u8* __restrict__ bytes,
+    const u64* __restrict__ byte_off, const u32* __restrict__ counts,
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks) {
+  __shared__ EncWaveLds s_lds[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  EncWaveLds& S = s_lds[wave];
+  const bool flat_role = blockIdx.x >= n_long_blocks;  // as in k_decode_batch2
+  const u32 K = flat_role ? 64u : K_long;
+  const u64 s0 = ((u64)(flat_role ? blockIdx.x - n_long_blocks : blockIdx.x) * kWaves + wave) * K;
+  if (s0 >= nstreams) return;  // wave-uniform; no workgroup barrier below
+  const bool valid = (u32)lane < K && s0 + lane < nstreams;
+  const u32 sid = (u32)(s0 + lane);
+  u32 cnt = 0, prev = 0;
+  u64 boff = 0, voff = 0;
+  if (valid) {
+    cnt = counts[sid];
+    boff = byte_off[sid];
+    voff = value_off[sid];
+    if (DELTA && prevs) prev = prevs[sid];
+  }
+  const bool is_short = valid && cnt > 0 && cnt <= kFlatMax;
+  const bool is_long = valid && cnt > kFlatMax;
+
+  if (flat_role) {
+  if (valid && cnt == 0) sizes[sid] = 0;
+  FlatEnt* ent = reinterpret_cast<FlatEnt*>(S.data);
+  u32 n_short, my_first;
+  const u32 n_slots = flat_setup(is_short, cnt, boff, voff, prev, sid, lane, ent, n_short, my_first);
+  u32 carry_idx = 0xFFFFFFFFu, carry_doff = 0;  // wave-uniform: the stream cut by the last step's end
+  for (u32 base = 0; base < n_slots; base += 64) {
+    const FlatSlot f = flat_slot(base, n_slots, n_short, my_first, lane, ent);
+    const u32* in = values + f.e.voff;
+    u8* out = bytes + f.e.boff;
+    const u32 keylen = (f.e.cnt + 3u) >> 2;
+    const u32 lim = f.have ? f.e.cnt : 0u;
+    const u32 nv = f.have ? min(4u, f.e.cnt - 4u * f.gi) : 0u;
+    uint4 c = load_group(in, 4ull * f.gi, lim);
+    if (DELTA) {
+      u32 p = f.e.prev;  // the value before the group's first: the stream's seed or the stream's own value
+      if (f.have && f.gi) p = in[4u * f.gi - 1u];
+      c = make_uint4(c.x - p, c.y - c.x, c.z - c.y, c.w - c.z);
+    }
+    if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
+    if (DELTA || ZZ) zero_absent(c, 4ull * f.gi, lim);
+    const u32 gd = classify_group<V, false>(c, nv);
+    const u32 L = gi_total(gd);
+    const u32 incl = seg_add_scan(f.idx, L) + (f.idx == carry_idx ? carry_doff : 0u);
+    if (f.have) {
+      u8* q = out + keylen + (incl - L);
+      out[f.gi] = (u8)gi_key(gd);
+      const uint4 d = pack_group<V>(c, gd);
+      if (L >= 4u) st_u32(q, d.x);
+      if (L >= 8u) st_u32(q + 4, d.y);
+      if (L >= 12u) st_u32(q + 8, d.z);
+      if (L >= 16u) st_u32(q + 12, d.w);
+      const u32 full = L & ~3u, rest = L & 3u;
+      const u32 t = full == 0u ? d.x : (full == 4u ? d.y : (full == 8u ? d.z : d.w));
+      if (rest >= 1u) q[full] = (u8)t;
+      if (rest >= 2u) q[full + 1] = (u8)(t >> 8);
+      if (rest >= 3u) q[full + 2] = (u8)(t >> 16);
+      if (f.gi == keylen - 1u) sizes[f.e.sid] = (u64)keylen + incl;
+    }
+    carry_idx = (u32)__builtin_amdgcn_readlane((int)f.idx, 63);
+    carry_doff = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+  }
+  return;
+  }
+
+  // ---- long streams, one after the other, the whole wavefront on a wave tile at a time ----
+  u64 todo = __ballot(is_long);
+  while (todo) {
+    const int src = (int)__builtin_ctzll(todo);
+    todo &= todo - 1ull;
+    const u32 count = (u32)__builtin_amdgcn_readlane((int)cnt, src);
+    const u64 lboff = ((u64)(u32)__builtin_amdgcn_readlane((int)(boff >> 32), src) << 32) |
+                      (u32)__builtin_amdgcn_readlane((int)boff, src);
+    const u64 lvoff = ((u64)(u32)__builtin_amdgcn_readlane((int)(voff >> 32), src) << 32) |
+                      (u32)__builtin_amdgcn_readlane((int)voff, src);
+    u32 carry = (u32)__builtin_amdgcn_readlane((int)prev, src);
+    const u32* in = values + lvoff;
+    u8* out = bytes + lboff;
+    const u64 keylen = ((u64)count + 3) >> 2;
+    const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+    u64 doff = 0;
+    for (u32 wt = 0; wt < n_wt; ++wt) {
+      const u64 int0 = (u64)wt * kWtInts;
+      const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
+      uint4 x[4];
+      u32 g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = load_group(in, int0 + 4u * (j * 64 + lane), count);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4 c = x[j];
+        if (DELTA) {
+          const u32 p = wave_shift_up1(c.w, carry);
+          carry = wave_last(c.w);
+          c = make_uint4(c.x - p, c.y - c.x, c.z - c.y, c.w - c.z);
+        }
+        if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
+        const u64 first = int0 + 4u * (j * 64 + lane);
+        if (DELTA || ZZ) zero_absent(c, first, count);
+        x[j] = c;
+        g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
+      }
+      doff += encode_wavetile<V, false>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
+    }
+    if (lane == 0) sizes[s0 + src] = keylen + doff;
+  }
+}
+
 template <int V, bool D, bool Z>
-void launch_decode_batch(unsigned grid, const uint8_t* d_bytes, const uint64_t* d_byte_off,
+void launch_decode_batch(unsigned grid, unsigned chunk, const uint8_t* d_bytes, const uint64_t* d_byte_off,
                          uint32_t* d_values, const uint64_t* d_value_off, const uint32_t* d_counts,
                          const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes,
                          hipStream_t st) {
+  if (chunk) {  // chunked kernel: long streams `chunk` of the batch's streams per wavefront, then the flat part
+    const unsigned long long long_blocks = (((unsigned long long)nstreams + chunk - 1) / chunk + kWaves - 1) / kWaves;
+    const unsigned long long flat_blocks = (((unsigned long long)nstreams + 63) / 64 + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL((k_decode_batch2<V, D, Z>), dim3((unsigned)(long_blocks + flat_blocks)), dim3(kBlock), 0, st,
+                       d_bytes, d_byte_off, d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes, chunk,
+                       (unsigned)long_blocks);
+    return;
+  }
   // short lists, four to a wavefront; then the long ones, one wavefront each
   const unsigned rows_grid = (unsigned)std::min<unsigned long long>(grid, ((unsigned long long)nstreams + 15) / 16);
   hipLaunchKernelGGL((k_decode_batch_rows<V, D, Z>), dim3(rows_grid ? rows_grid : 1), dim3(kBlock), 0, st,
@@ -237,10 +541,18 @@ void launch_decode_batch(unsigned grid, const uint8_t* d_bytes, const uint64_t* 
                      d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes, kRowMax + 1);
 }
 template <int V, bool D, bool Z>
-void launch_encode_batch(unsigned grid, const uint32_t* d_values, const uint64_t* d_value_off,
+void launch_encode_batch(unsigned grid, unsigned chunk, const uint32_t* d_values, const uint64_t* d_value_off,
                          uint8_t* d_bytes, const uint64_t* d_byte_off, const uint32_t* d_counts,
                          const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes,
                          hipStream_t st) {
+  if (chunk) {
+    const unsigned long long long_blocks = (((unsigned long long)nstreams + chunk - 1) / chunk + kWaves - 1) / kWaves;
+    const unsigned long long flat_blocks = (((unsigned long long)nstreams + 63) / 64 + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL((k_encode_batch2<V, D, Z>), dim3((unsigned)(long_blocks + flat_blocks)), dim3(kBlock), 0, st,
+                       d_values, d_value_off, d_bytes, d_byte_off, d_counts, d_prev, nstreams, d_sizes, chunk,
+                       (unsigned)long_blocks);
+    return;
+  }
   const unsigned rows_grid = (unsigned)std::min<unsigned long long>(grid, ((unsigned long long)nstreams + 15) / 16);
   hipLaunchKernelGGL((k_encode_batch_rows<V, D, Z>), dim3(rows_grid ? rows_grid : 1), dim3(kBlock), 0, st,
                      d_values, d_value_off, d_bytes, d_byte_off, d_counts, d_prev, nstreams, d_sizes);

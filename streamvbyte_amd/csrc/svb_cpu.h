@@ -1,0 +1,337 @@
+// Host-side codec of libstreamvbyte.so.2: what the reference-named functions run
+// when the work is too small to be worth a trip over PCIe, or when the process
+// has no gfx950 device at all.  Written for this library; it shares no code with
+// the test oracle and is never used by the svbgpu_* device-pointer API.
+//
+// Stream format and return values are those of the reference
+// (src/streamvbyte_encode.c:14-62,113-137, src/streamvbyte_decode.c:18-87,
+// src/streamvbyte_0124_encode.c:12-57,96-113, src/streamvbyte_0124_decode.c:38-79,165-229,
+// src/streamvbytedelta_encode.c:39-76, src/streamvbytedelta_decode.c:34-74,
+// src/streamvbyte_zigzag.c:3-38).  Two tiers:
+//   * portable scalar loops (any x86-64 / any host), and
+//   * an SSSE3 decoder for whole groups of four values (one byte shuffle per
+//     group, masks built at first use from the width rule, not stored tables),
+//     chosen at run time with __builtin_cpu_supports.
+// Buffer rules as in the reference: decoders may read up to 16 bytes past the
+// stream (STREAMVBYTE_PADDING) and write exactly `count` values; encoders write
+// only inside streamvbyte_max_compressedbytes(count).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace svbcpu {
+
+constexpr int k1234 = 0;
+constexpr int k0124 = 1;
+
+// ---- width rule ----------------------------------------------------------------
+// 1234: code = number of bytes needed - 1; 0124: 0 for zero, 1 / 2 for one / two
+// bytes, 3 (four bytes) for anything wider than two bytes.
+inline unsigned code_1234(uint32_t v) { return (31u - (unsigned)__builtin_clz(v | 1u)) >> 3; }
+inline unsigned code_0124(uint32_t v) {
+  if (v == 0) return 0;
+  const unsigned bytes = ((31u - (unsigned)__builtin_clz(v)) >> 3) + 1u;  // 1..4
+  return bytes >= 3 ? 3u : bytes;
+}
+inline unsigned len_1234(unsigned code) { return code + 1u; }
+inline unsigned len_0124(unsigned code) { return (1u << code) >> 1; }
+
+template <int V>
+inline unsigned code_of(uint32_t v) { return V == k1234 ? code_1234(v) : code_0124(v); }
+template <int V>
+inline unsigned len_of(unsigned code) { return V == k1234 ? len_1234(code) : len_0124(code); }
+
+// ---- scalar encode ----------------------------------------------------------------
+// Encodes values [first, count) (first % 4 == 0) behind what keys / data already hold.
+template <int V, bool DELTA>
+uint8_t* encode_scalar_from(const uint32_t* in, uint32_t first, uint32_t count, uint8_t* keys, uint8_t* data,
+                            uint32_t prev) {
+  for (uint32_t i = first; i < count;) {
+    unsigned key = 0;
+    const uint32_t in_group = count - i < 4 ? count - i : 4;
+    for (uint32_t k = 0; k < in_group; ++k, ++i) {
+      uint32_t v = in[i];
+      if (DELTA) {
+        const uint32_t cur = v;
+        v = cur - prev;  // uint32 wrap-around: the input need not be sorted
+        prev = cur;
+      }
+      const unsigned c = code_of<V>(v);
+      key |= c << (2 * k);
+      // all four bytes are stored (little-endian host) and the pointer moves on by the value's
+      // length: the spare bytes are overwritten by the next value or lie inside the 16 bytes of
+      // slack of streamvbyte_max_compressedbytes
+      std::memcpy(data, &v, 4);
+      data += len_of<V>(c);
+    }
+    *keys++ = (uint8_t)key;
+  }
+  return data;
+}
+
+template <int V, bool DELTA>
+size_t encode(const uint32_t* in, uint32_t count, uint8_t* out, uint32_t prev);
+
+// ---- scalar decode ----------------------------------------------------------------
+template <int V>
+inline uint32_t read_value(const uint8_t* p, unsigned len) {
+  uint32_t v = 0;
+  for (unsigned b = 0; b < len; ++b) v |= (uint32_t)p[b] << (8 * b);
+  return v;
+}
+// Decodes values [first, count) given the key pointer / data pointer at `first` (first % 4 == 0).
+template <int V, bool DELTA>
+const uint8_t* decode_scalar_from(const uint8_t* keys, const uint8_t* data, uint32_t* out, uint32_t first,
+                                  uint32_t count, uint32_t& prev) {
+  for (uint32_t i = first; i < count;) {
+    const unsigned key = *keys++;
+    const uint32_t in_group = count - i < 4 ? count - i : 4;
+    for (uint32_t k = 0; k < in_group; ++k, ++i) {
+      const unsigned len = len_of<V>((key >> (2 * k)) & 3u);
+      uint32_t v = read_value<V>(data, len);
+      data += len;
+      if (DELTA) {
+        v += prev;
+        prev = v;
+      }
+      out[i] = v;
+    }
+  }
+  return data;
+}
+
+#if defined(__x86_64__)
+// ---- SSE4.1 encode of whole groups ----------------------------------------------------
+// Four values at a time: widths from three unsigned compares, the key byte by one
+// multiply, the data bytes compacted by one byte shuffle whose mask is looked up
+// by the key (built at first use from the width rule).  A 16-byte store per group
+// stays inside streamvbyte_max_compressedbytes.
+struct PackTables {
+  alignas(16) uint8_t mask[2][256][16];
+  uint8_t len[2][256];
+  PackTables() {
+    for (int variant = 0; variant < 2; ++variant)
+      for (int key = 0; key < 256; ++key) {
+        unsigned pos = 0;
+        for (unsigned b = 0; b < 16; ++b) mask[variant][key][b] = 0x80;
+        for (int k = 0; k < 4; ++k) {
+          const unsigned code = (key >> (2 * k)) & 3u;
+          const unsigned n = variant == k1234 ? len_1234(code) : len_0124(code);
+          for (unsigned b = 0; b < n; ++b) mask[variant][key][pos + b] = (uint8_t)(4 * k + b);
+          pos += n;
+        }
+        len[variant][key] = (uint8_t)pos;
+      }
+  }
+};
+inline const PackTables& pack_tables() {
+  static const PackTables t;
+  return t;
+}
+inline bool have_sse41() {
+  static const bool ok = __builtin_cpu_supports("sse4.1");
+  return ok;
+}
+template <int V, bool DELTA>
+__attribute__((target("sse4.1"))) uint32_t encode_groups_sse41(const uint32_t* in, uint32_t count, uint8_t*& keys,
+                                                                uint8_t*& data, uint32_t& prev) {
+  const PackTables& T = pack_tables();
+  const uint32_t groups = count / 4;
+  // thresholds: a value at or below t[i] needs no byte beyond the i-th class
+  const __m128i t1 = _mm_set1_epi32(V == k1234 ? 0xFF : 0), t2 = _mm_set1_epi32(V == k1234 ? 0xFFFF : 0xFF),
+                t3 = _mm_set1_epi32(V == k1234 ? 0xFFFFFF : 0xFFFF);
+  const __m128i three = _mm_set1_epi32(3);
+  const __m128i gather = _mm_setr_epi8(0, 4, 8, 12, -128, -128, -128, -128, -128, -128, -128, -128, -128, -128, -128, -128);
+  __m128i before = _mm_set1_epi32((int)prev);
+  uint8_t* d = data;
+  for (uint32_t g = 0; g < groups; ++g) {
+    __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in + 4 * (size_t)g));
+    if (DELTA) {
+      const __m128i shifted = _mm_alignr_epi8(v, before, 12);  // {prev, v0, v1, v2}
+      before = v;
+      v = _mm_sub_epi32(v, shifted);
+    }
+    // code = 3 - [v <= t1] - [v <= t2] - [v <= t3]  (each compare gives -1 where true)
+    __m128i c = _mm_add_epi32(three, _mm_cmpeq_epi32(_mm_min_epu32(v, t1), v));
+    c = _mm_add_epi32(c, _mm_cmpeq_epi32(_mm_min_epu32(v, t2), v));
+    c = _mm_add_epi32(c, _mm_cmpeq_epi32(_mm_min_epu32(v, t3), v));
+    const uint32_t packed = (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(c, gather));  // one code per byte
+    const unsigned key = (packed * 0x01041040u) >> 24;  // c0 | c1 << 2 | c2 << 4 | c3 << 6
+    keys[g] = (uint8_t)key;
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(d),
+                     _mm_shuffle_epi8(v, _mm_load_si128(reinterpret_cast<const __m128i*>(T.mask[V][key]))));
+    d += T.len[V][key];
+  }
+  if (DELTA && groups) prev = in[4 * (size_t)groups - 1];
+  keys += groups;
+  data = d;
+  return groups * 4;
+}
+
+// ---- SSSE3 decode of whole groups ----------------------------------------------------
+// For every key byte: the pshufb mask that spreads the group's packed bytes over
+// four 32-bit lanes (0x80 = zero fill) and the group's data length.  Built once
+// from the width rule.
+struct ShuffleTables {
+  alignas(16) uint8_t mask[2][256][16];
+  uint8_t len[2][256];
+  ShuffleTables() {
+    for (int variant = 0; variant < 2; ++variant)
+      for (int key = 0; key < 256; ++key) {
+        unsigned pos = 0;
+        for (int k = 0; k < 4; ++k) {
+          const unsigned code = (key >> (2 * k)) & 3u;
+          const unsigned n = variant == k1234 ? len_1234(code) : len_0124(code);
+          for (unsigned b = 0; b < 4; ++b) mask[variant][key][4 * k + b] = b < n ? (uint8_t)(pos + b) : 0x80;
+          pos += n;
+        }
+        len[variant][key] = (uint8_t)pos;
+      }
+  }
+};
+inline const ShuffleTables& tables() {
+  static const ShuffleTables t;  // thread-safe initialisation (C++11 magic static)
+  return t;
+}
+inline bool have_ssse3() {
+  static const bool ok = __builtin_cpu_supports("ssse3");
+  return ok;
+}
+
+// Decodes every whole group (count / 4 of them): a 16-byte load at the group's
+// first data byte stays inside the stream plus its 16 bytes of padding, a
+// 16-byte store inside out[0 .. count).  Returns the number of values decoded;
+// keys / data / prev advance.
+template <int V, bool DELTA>
+__attribute__((target("ssse3"))) uint32_t decode_groups_ssse3(const uint8_t*& keys, const uint8_t*& data,
+                                                               uint32_t* out, uint32_t count, uint32_t& prev) {
+  const ShuffleTables& T = tables();
+  const uint32_t groups = count / 4;  // only full groups
+  __m128i run = _mm_set1_epi32((int)prev);
+  uint32_t g = 0;
+  const uint8_t* k = keys;
+  const uint8_t* d = data;
+  for (; g < groups; ++g) {
+    const unsigned key = k[g];
+    const __m128i bytes = _mm_loadu_si128(reinterpret_cast<const __m128i*>(d));  // may read past the group: padding
+    __m128i v = _mm_shuffle_epi8(bytes, _mm_load_si128(reinterpret_cast<const __m128i*>(T.mask[V][key])));
+    d += T.len[V][key];
+    if (DELTA) {
+      // inclusive prefix sum inside the register, then the carry of the previous group
+      v = _mm_add_epi32(v, _mm_slli_si128(v, 4));
+      v = _mm_add_epi32(v, _mm_slli_si128(v, 8));
+      v = _mm_add_epi32(v, run);
+      run = _mm_shuffle_epi32(v, 0xFF);
+    }
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(out + 4 * (size_t)g), v);
+  }
+  if (DELTA) prev = (uint32_t)_mm_cvtsi128_si32(run);
+  keys = k + groups;
+  data = d;
+  return groups * 4;
+}
+#endif
+
+template <int V, bool DELTA>
+size_t decode(const uint8_t* in, uint32_t* out, uint32_t count, uint32_t prev) {
+  if (count == 0) return 0;
+  const size_t keylen = ((size_t)count + 3) / 4;
+  const uint8_t* keys = in;
+  const uint8_t* data = in + keylen;
+  uint32_t done = 0;
+#if defined(__x86_64__)
+  if (count >= 8 && have_ssse3()) done = decode_groups_ssse3<V, DELTA>(keys, data, out, count, prev);
+#endif
+  data = decode_scalar_from<V, DELTA>(keys, data, out, done, count, prev);
+  return (size_t)(data - in);
+}
+
+template <int V, bool DELTA>
+size_t encode(const uint32_t* in, uint32_t count, uint8_t* out, uint32_t prev) {
+  if (count == 0) return 0;
+  const size_t keylen = ((size_t)count + 3) / 4;
+  uint8_t* keys = out;
+  uint8_t* data = out + keylen;
+  uint32_t done = 0;
+#if defined(__x86_64__)
+  if (count >= 8 && have_sse41()) done = encode_groups_sse41<V, DELTA>(in, count, keys, data, prev);
+#endif
+  data = encode_scalar_from<V, DELTA>(in, done, count, keys, data, prev);
+  return (size_t)(data - out);
+}
+
+template <int V>
+size_t compressedbytes(const uint32_t* in, uint32_t count) {
+  size_t bytes = ((size_t)count + 3) / 4;
+  for (uint32_t i = 0; i < count; ++i) bytes += len_of<V>(code_of<V>(in[i]));
+  return bytes;
+}
+
+// The reference's rule (src/streamvbyte_decode.c:89-136): an empty stream is valid
+// only for an empty output; the key block must fit; the lengths the first `count`
+// codes promise must add up to exactly the bytes behind the key block.
+template <int V>
+bool validate(const uint8_t* in, size_t in_length, uint32_t count) {
+  if (in_length == 0 || count == 0) return in_length == (size_t)count;
+  const size_t keylen = ((size_t)count + 3) / 4;
+  if (keylen > in_length) return false;
+  uint64_t promised = 0;
+  const size_t full = count / 4;
+  for (size_t k = 0; k < full; ++k) {
+    const unsigned key = in[k];
+    for (int j = 0; j < 4; ++j) promised += len_of<V>((key >> (2 * j)) & 3u);
+  }
+  if (count & 3u) {
+    const unsigned key = in[full];
+    for (unsigned j = 0; j < (count & 3u); ++j) promised += len_of<V>((key >> (2 * j)) & 3u);
+  }
+  return promised == (uint64_t)(in_length - keylen);
+}
+
+inline uint32_t zz_enc(int32_t v) { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); }
+inline int32_t zz_dec(uint32_t u) { return (int32_t)((u >> 1) ^ (0u - (u & 1u))); }
+
+inline void zigzag(int mode, const void* in_, void* out_, size_t n, int32_t prev) {
+  if (mode == 0) {
+    const int32_t* in = static_cast<const int32_t*>(in_);
+    uint32_t* out = static_cast<uint32_t*>(out_);
+    for (size_t i = 0; i < n; ++i) out[i] = zz_enc(in[i]);
+  } else if (mode == 1) {
+    const uint32_t* in = static_cast<const uint32_t*>(in_);
+    int32_t* out = static_cast<int32_t*>(out_);
+    for (size_t i = 0; i < n; ++i) out[i] = zz_dec(in[i]);
+  } else if (mode == 2) {
+    const int32_t* in = static_cast<const int32_t*>(in_);
+    uint32_t* out = static_cast<uint32_t*>(out_);
+    for (size_t i = 0; i < n; ++i) {
+      const int32_t cur = in[i];
+      out[i] = zz_enc((int32_t)((uint32_t)cur - (uint32_t)prev));  // wrap-around difference
+      prev = cur;
+    }
+  } else {
+    const uint32_t* in = static_cast<const uint32_t*>(in_);
+    int32_t* out = static_cast<int32_t*>(out_);
+    for (size_t i = 0; i < n; ++i) {
+      prev = (int32_t)((uint32_t)zz_dec(in[i]) + (uint32_t)prev);
+      out[i] = prev;
+    }
+  }
+}
+
+// ---- run-time dispatch on variant / delta --------------------------------------------
+inline size_t encode_any(int variant, bool delta, const uint32_t* in, uint32_t count, uint8_t* out, uint32_t prev) {
+  if (variant == k1234) return delta ? encode<k1234, true>(in, count, out, prev) : encode<k1234, false>(in, count, out, 0);
+  return delta ? encode<k0124, true>(in, count, out, prev) : encode<k0124, false>(in, count, out, 0);
+}
+inline size_t decode_any(int variant, bool delta, const uint8_t* in, uint32_t* out, uint32_t count, uint32_t prev) {
+  if (variant == k1234) return delta ? decode<k1234, true>(in, out, count, prev) : decode<k1234, false>(in, out, count, 0);
+  return delta ? decode<k0124, true>(in, out, count, prev) : decode<k0124, false>(in, out, count, 0);
+}
+
+}  // namespace svbcpu

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(1024) void k_scan_super(const u32* __restrict__ sup
 
 // ---------------------------------------------------------------------------
 // Per-wave LDS: 256 entries (data offset | key<<16) + the wave tile's data span.
+// (Measured: 16-bit offsets and key bytes in arrays of their own bring the wave's
+// share under 5 KiB and an eighth workgroup onto the CU, but the two narrow LDS
+// reads per group instead of one dword cost k_decode 8 %.)
 struct __align__(16) WaveLds {
   u32 ent[kWtKeys];
   u8 data[kWtDataMax + 48];  // +16 alignment slack, +16 partial chunk, +slack for 8-byte over-read

@@ -96,6 +96,36 @@ __device__ __forceinline__ u32 wave_shift_up1(u32 x, u32 first) {
 __device__ __forceinline__ u32 wave_shift_down1(u32 x, u32 last) {
   return (u32)__builtin_amdgcn_update_dpp((int)last, (int)x, 0x130, 0xF, 0xF, false);  // wave_shl:1
 }
+// Segmented inclusive prefix sum over the lanes: lane l ends up with the sum of
+// val over the lanes l' <= l that have the same key.  Keys must not decrease
+// with the lane.  The six DPP steps of wave_scan_incl; a step contributes only
+// where the key it brings along equals the lane's own (keys are sorted, so then
+// every lane in between has that key too).  Lanes without a source see val 0.
+__device__ __forceinline__ u32 seg_add_scan(u32 key, u32 val) {
+#define SVB_SEG_STEP(CTRL, MASK)                                                \
+  {                                                                             \
+    const u32 k2 = dpp_zero<CTRL, MASK>(key), v2 = dpp_zero<CTRL, MASK>(val);   \
+    val += k2 == key ? v2 : 0u;                                                 \
+  }
+  SVB_SEG_STEP(0x111, 0xF)
+  SVB_SEG_STEP(0x112, 0xF)
+  SVB_SEG_STEP(0x114, 0xF)
+  SVB_SEG_STEP(0x118, 0xF)
+  SVB_SEG_STEP(0x142, 0xA)
+  SVB_SEG_STEP(0x143, 0xC)
+#undef SVB_SEG_STEP
+  return val;
+}
+// OR of x over the wavefront (wave-uniform result).
+__device__ __forceinline__ u32 wave_or(u32 x) {
+  x |= dpp_zero<0x111, 0xF>(x);
+  x |= dpp_zero<0x112, 0xF>(x);
+  x |= dpp_zero<0x114, 0xF>(x);
+  x |= dpp_zero<0x118, 0xF>(x);
+  x |= dpp_zero<0x142, 0xA>(x);
+  x |= dpp_zero<0x143, 0xC>(x);
+  return wave_last(x);
+}
 __device__ __forceinline__ u32 wave_sum(u32 x) { return wave_last(wave_scan_incl(x, 0)); }
 // 64-bit sum over the wavefront as three 32-bit DPP reductions of 26-bit pieces
 // (a chain of twelve ds_bpermute shuffles costs several hundred cycles).

@@ -13,11 +13,49 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def svb():
+    """Every call of this module goes to the kernels: the cutoff below which the reference-named
+    functions run on the host codec is switched off (tests/test_host_codec.py covers that codec)."""
     import torch
     assert torch.cuda.is_available()
     import streamvbyte_amd
-    streamvbyte_amd.load()
-    return streamvbyte_amd
+    lib = streamvbyte_amd.load()
+    assert lib.svbgpu_set_option(b"host_cpu_cutoff", 0) == 0
+    yield streamvbyte_amd
+    lib.svbgpu_set_option(b"host_cpu_cutoff", 1 << 16)
+
+
+def test_small_host_calls_take_the_host_codec_by_default(svb, oracle):
+    """With the default cutoff a small host-pointer call is answered without the GPU (same bytes),
+    and a device pointer goes to the kernels whatever its size."""
+    import time
+    import torch
+    lib = svb.load()
+    v = GENERATORS["width_mix"](np.random.default_rng(2), 1000)
+    expect = oracle.encode(V1234, v)
+    out = np.zeros(svb.streamvbyte_max_compressedbytes(v.size), dtype=np.uint8)
+    try:
+        lib.svbgpu_set_option(b"host_cpu_cutoff", 1 << 16)
+        lib.streamvbyte_encode(v.ctypes.data, v.size, out.ctypes.data)  # warm
+        t0 = time.perf_counter()
+        for _ in range(50):
+            n = lib.streamvbyte_encode(v.ctypes.data, v.size, out.ctypes.data)
+        host_us = (time.perf_counter() - t0) / 50 * 1e6
+        assert n == expect.size and np.array_equal(out[:n], expect)
+        lib.svbgpu_set_option(b"host_cpu_cutoff", 0)
+        lib.streamvbyte_encode(v.ctypes.data, v.size, out.ctypes.data)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            n = lib.streamvbyte_encode(v.ctypes.data, v.size, out.ctypes.data)
+        gpu_us = (time.perf_counter() - t0) / 50 * 1e6
+        assert n == expect.size and np.array_equal(out[:n], expect)
+        assert host_us < gpu_us, (host_us, gpu_us)  # that is what the cutoff is for
+        lib.svbgpu_set_option(b"host_cpu_cutoff", 1 << 16)
+        d_v = torch.from_numpy(v.view(np.int32)).cuda()
+        d_out = torch.zeros(out.size, dtype=torch.uint8, device="cuda:0")
+        n = lib.streamvbyte_encode(d_v.data_ptr(), v.size, d_out.data_ptr())
+        assert n == expect.size and np.array_equal(d_out[:n].cpu().numpy(), expect)
+    finally:
+        lib.svbgpu_set_option(b"host_cpu_cutoff", 0)
 
 
 def test_issue42(svb, golden):

@@ -11,7 +11,7 @@ tot = 1 << 27
 codec = svb.DeviceCodec(1 << 20, dev)
 g = torch.Generator(device=dev); g.manual_seed(1)
 gaps = torch.randint(0, 1 << 12, (tot,), generator=g, device=dev, dtype=torch.int64)
-for L in (16, 64, 256, 1000, 1024, 4096, 16384, 1 << 20):
+for L in (4, 16, 64, 256, 300, 512, 1000, 1024, 1100, 1536, 4096, 16384):
     nl = tot // L
     n = nl * L
     vals = gaps[:n].to(torch.int32).contiguous()
