@@ -149,24 +149,24 @@ int check_ws(uint32_t count, void* ws, size_t ws_bytes) {
 // header + look-back words start every call at zero
 int clear_lookback(uint32_t count, void* ws, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  return fill_u32(ws, 0u, L.off_super_off, st);
+  return fill_u32(ws, 0u, L.off_mega_sum, st);
 }
 
 // ---- offset directory -------------------------------------------------------
 int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, hipStream_t st) {
   const WsLayout L = ws_layout(count);
   u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
-  u32* super_sum = ws_at<u32>(ws, L.off_super_sum);
-  u64* super_off = ws_at<u64>(ws, L.off_super_off);
-  const unsigned grid = stream_grid(L.n_super, 0);
+  u32* mega_sum = ws_at<u32>(ws, L.off_mega_sum);
+  const u32 spm = L.wt_per_mega / kSuperWt;
   if (variant == SVBGPU_1234)
-    hipLaunchKernelGGL(k_key_sums<V1234>, dim3(grid), dim3(kBlock), 0, st, d_in, count, wt_rel, super_sum);
+    hipLaunchKernelGGL(k_key_sums<V1234>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
   else
-    hipLaunchKernelGGL(k_key_sums<V0124>, dim3(grid), dim3(kBlock), 0, st, d_in, count, wt_rel, super_sum);
-  hipLaunchKernelGGL(k_scan_super, dim3(1), dim3(1024), 0, st, super_sum, super_off,
-                     (u32)L.n_super, &ws_hdr(ws)->total_data);
+    hipLaunchKernelGGL(k_key_sums<V0124>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
+}
+inline Dir ws_dir(void* ws, const WsLayout& L) {
+  return Dir{ws_at<u32>(ws, L.off_mega_sum), ws_at<u32>(ws, L.off_wt_rel), L.wt_per_mega};
 }
 
 template <int V, bool ZZ>
@@ -176,10 +176,10 @@ void launch_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint3
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, o.decode_per_cu);
   if (o.decode_shortcut)
     hipLaunchKernelGGL((k_decode<V, ZZ, true>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
-                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed, 0u);
+                       ws_dir(ws, L), d_consumed, 0u);
   else
     hipLaunchKernelGGL((k_decode<V, ZZ, false>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
-                       ws_at<u64>(ws, L.off_super_off), ws_at<u32>(ws, L.off_wt_rel), d_consumed, 0u);
+                       ws_dir(ws, L), d_consumed, 0u);
 }
 template <int V, bool ZZ>
 void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
@@ -187,18 +187,15 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
   const WsLayout L = ws_layout(count);
   if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
     hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024), 0, st, d_in,
-                       d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
-                       ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
+                       d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
   else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st, d_in,
-                       d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
-                       ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
+                       d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
   else
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
-                     d_out, count, prev, ws_at<u64>(ws, L.off_super_off),
-                     ws_at<u32>(ws, L.off_wt_rel), ws_hdr(ws),
+                     d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
 }
 
@@ -207,16 +204,15 @@ void launch_delta_decode2(const Options& o, const uint8_t* d_in, uint32_t* d_out
                           void* ws, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, o.decode_per_cu);
-  u64* super_off = ws_at<u64>(ws, L.off_super_off);
-  u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
+  const Dir dir = ws_dir(ws, L);
   u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
   u32* blk = ws_at<u32>(ws, L.off_blk);
   const unsigned nblk = (unsigned)((L.n_wt + 1023) / 1024);
-  hipLaunchKernelGGL((k_value_sums<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, count, super_off, wt_rel, vsum);
+  hipLaunchKernelGGL((k_value_sums<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, count, dir, vsum);
   hipLaunchKernelGGL(k_scan_u32_blocks, dim3(nblk), dim3(kBlock), 0, st, vsum, (u32)L.n_wt, blk);
   hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, st, blk, nblk, prev);
-  hipLaunchKernelGGL((k_delta_decode2<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count, super_off,
-                     wt_rel, vsum, blk, d_consumed);
+  hipLaunchKernelGGL((k_delta_decode2<V, ZZ>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count, dir, vsum, blk,
+                     d_consumed);
 }
 
 // decode with the directory already in the workspace
@@ -566,15 +562,14 @@ int svbgpu_decode_dequantize(int variant, const uint8_t* d_in, float* d_out, uin
   const WsLayout L = ws_layout(count);
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, options().decode_per_cu);
   u32* out = reinterpret_cast<u32*>(d_out);
-  u64* so = ws_at<u64>(ws, L.off_super_off);
-  u32* wr = ws_at<u32>(ws, L.off_wt_rel);
+  const Dir dir = ws_dir(ws, L);
   hipStream_t st = S(stream);
   if (variant == SVBGPU_1234) {
-    if (accumulate) hipLaunchKernelGGL((k_decode<V1234, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
-    else            hipLaunchKernelGGL((k_decode<V1234, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
+    if (accumulate) hipLaunchKernelGGL((k_decode<V1234, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
+    else            hipLaunchKernelGGL((k_decode<V1234, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
   } else {
-    if (accumulate) hipLaunchKernelGGL((k_decode<V0124, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
-    else            hipLaunchKernelGGL((k_decode<V0124, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, so, wr, d_consumed, bits);
+    if (accumulate) hipLaunchKernelGGL((k_decode<V0124, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
+    else            hipLaunchKernelGGL((k_decode<V0124, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
   }
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
@@ -606,12 +601,14 @@ int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32
   if (!d_in) return SVBGPU_EINVAL;
   WsHeader* h = ws_hdr(ws);
   { int rc0 = fill_u32(&h->accum, 0u, 8, S(stream)); if (rc0) return rc0; }
-  const unsigned grid = stream_grid(((keylen + 15) / 16 + kBlock - 1) / kBlock, 2);
+  // a workgroup per CU at most; at least 16 KiB of keys (one load per thread) each
+  // a workgroup of 1024 threads per CU at most, at least 16 KiB of keys (one load per thread) each
+  const unsigned grid = stream_grid((keylen + 16383) / 16384, 1);
   if (variant == SVBGPU_1234)
-    hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count,
+    hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(1024), 0, S(stream), d_in, count,
                        (u64)in_length, &h->accum, d_ok);
   else
-    hipLaunchKernelGGL(k_validate_sum<V0124>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count,
+    hipLaunchKernelGGL(k_validate_sum<V0124>, dim3(grid), dim3(1024), 0, S(stream), d_in, count,
                        (u64)in_length, &h->accum, d_ok);
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
@@ -677,12 +674,11 @@ void launch_intersect(const uint8_t* d_in, uint32_t count, uint32_t prev, const 
                       hipStream_t st) {
   const WsLayout L = ws_layout(count);
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, options().decode_per_cu);
-  u64* super_off = ws_at<u64>(ws, L.off_super_off);
-  u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
+  const Dir dir = ws_dir(ws, L);
   u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
   u32* blk = ws_at<u32>(ws, L.off_blk);
   const unsigned nblk = (unsigned)((L.n_wt + 1023) / 1024);
-  hipLaunchKernelGGL((k_value_sums<V, false>), dim3(grid), dim3(kBlock), 0, st, d_in, count, super_off, wt_rel, vsum);
+  hipLaunchKernelGGL((k_value_sums<V, false>), dim3(grid), dim3(kBlock), 0, st, d_in, count, dir, vsum);
   hipLaunchKernelGGL(k_scan_u32_blocks, dim3(nblk), dim3(kBlock), 0, st, vsum, (u32)L.n_wt, blk);
   hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, st, blk, nblk, prev);
   u32* bound = ws_at<u32>(ws, L.off_bounds);
@@ -690,8 +686,7 @@ void launch_intersect(const uint8_t* d_in, uint32_t count, uint32_t prev, const 
   if (n_sorted)
     hipLaunchKernelGGL(k_wave_bounds, dim3((n_waves + kBlock - 1) / kBlock), dim3(kBlock), 0, st, vsum, blk, n_waves,
                        d_sorted, n_sorted, bound);
-  hipLaunchKernelGGL((k_delta_intersect<V>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count, super_off,
-                     wt_rel, vsum, blk, d_sorted, n_sorted, bound, d_out, d_n_out, (u32)L.n_tiles, ws_hdr(ws),
+  hipLaunchKernelGGL((k_delta_intersect<V>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count, dir, vsum, blk, d_sorted, n_sorted, bound, d_out, d_n_out, (u32)L.n_tiles, ws_hdr(ws),
                      LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
 }
 }  // extern "C++"
@@ -803,6 +798,7 @@ struct Ctx {
   void* hdir = nullptr;    size_t hdir_cap = 0;  // ... and its page-locked host image
   uint64_t* d_res = nullptr;                    // 64 bytes of device results
   uint64_t* h_res = nullptr;                    // pinned mirror
+  void* h_sums = nullptr;                       // pinned, 1 KiB: the directory's mega tile sums
   uint8_t* stage[2] = {nullptr, nullptr};       // page-locked staging chunks for pageable caller memory
   hipEvent_t stage_ev[2] = {nullptr, nullptr};  // the chunk's last copy has ended
 };
@@ -828,6 +824,7 @@ Ctx* ctx_acquire() {
   HIP_OR_DIE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_OR_DIE(hipMalloc(&c->d_res, 64));
   HIP_OR_DIE(hipHostMalloc(&c->h_res, 64, hipHostMallocDefault));
+  HIP_OR_DIE(hipHostMalloc(&c->h_sums, 4 * kMegas, hipHostMallocDefault));
   for (int k = 0; k < 2; ++k) {
     HIP_OR_DIE(hipHostMalloc(&c->stage[k], kStageChunk, hipHostMallocDefault));
     HIP_OR_DIE(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
@@ -988,6 +985,16 @@ void order_after_callers_work(std::initializer_list<const void*> ptrs) {
       return;
     }
 }
+// Data bytes of the stream whose directory is in the context's workspace: the sum of its mega tile sums.
+uint64_t fetch_total_data(Ctx* c, uint32_t count) {
+  const WsLayout L = ws_layout(count);
+  uint32_t* h = reinterpret_cast<uint32_t*>(c->h_sums);
+  HIP_OR_DIE(hipMemcpyAsync(h, ws_at<u32>(c->ws, L.off_mega_sum), 4 * L.n_mega, hipMemcpyDeviceToHost, c->stream));
+  HIP_OR_DIE(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  for (u32 m = 0; m < L.n_mega; ++m) total += h[m];
+  return total;
+}
 void check_scan(Ctx* c) {
   HIP_OR_DIE(hipMemcpyAsync(c->h_res + 2, c->ws, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_OR_DIE(hipStreamSynchronize(c->stream));
@@ -1040,7 +1047,7 @@ size_t decode_any(int variant, unsigned flags, const uint8_t* in, uint32_t* out,
     COPY_OR_DIE(copy_in(c, c->a, in, keylen));
     rc = build_directory(variant, static_cast<const uint8_t*>(c->a), count, c->ws, c->stream);
     if (rc) die("decode (key scan)", rc);
-    const uint64_t total = fetch_u64(c, &ws_hdr(c->ws)->total_data);  // data bytes of the stream
+    const uint64_t total = fetch_total_data(c, count);  // data bytes of the stream
     if (c->a_cap < keylen + total + 16) {
       grow(c->a, c->a_cap, keylen + total + 16);
       COPY_OR_DIE(copy_in(c, c->a, in, keylen + total));

@@ -9,91 +9,67 @@
 namespace svb {
 
 // ---------------------------------------------------------------------------
-// k_key_sums: one super tile (64 wave tiles = 16384 keys) per workgroup and round.
-// Thread t, round i reads the 16 keys at i*4096 + 16*t, so every 16 lanes cover
-// one wave tile; a 16-lane reduction gives the wave tile's data bytes.  Wave 0
-// then scans the 64 sums: wt_rel[] = data offset of each wave tile inside its
-// super tile, super_sum[] = data bytes of the super tile.
-// Reads 0.25 B per value, writes 4 B per 1024 values.
+// k_key_sums: the offset directory (see Dir) in one pass, one workgroup of 1024
+// threads per mega tile.  A round takes one super tile (16 KiB of keys = 64 wave
+// tiles): thread t reads the 16 keys at 16 t, so every 16 lanes cover one wave
+// tile and a row reduction gives its data bytes; wave 0 scans the 64 sums behind
+// the running offset of the mega tile while the other waves are already in the
+// next round (the sums are double-buffered, one barrier per round).  The loads of
+// the next kDirAhead rounds are in flight.  Reads 0.25 B per value, writes 4 B
+// per 1024 values; no scan kernel behind it, no atomics, nothing to clear.
+constexpr int kDirAhead = 6;
 template <int V>
-__global__ __launch_bounds__(kBlock) void k_key_sums(const u8* __restrict__ in, u32 count,
-                                                     u32* __restrict__ wt_rel,
-                                                     u32* __restrict__ super_sum) {
-  __shared__ u32 s_sum[kSuperWt];
+__global__ __launch_bounds__(1024) void k_key_sums(const u8* __restrict__ in, u32 count,
+                                                   u32* __restrict__ wt_rel, u32* __restrict__ mega_sum,
+                                                   u32 supers_per_mega) {
+  __shared__ u32 s_sum[2][kSuperWt];
   const u64 keylen = ((u64)count + 3) >> 2;
   const u64 n_wt = (keylen + kWtKeys - 1) / kWtKeys;
-  const int t = threadIdx.x;
   const u64 n_super = (n_wt + kSuperWt - 1) / kSuperWt;
-  for (u64 sb = blockIdx.x; sb < n_super; sb += gridDim.x) {
-  const u64 key_base = sb * (kSuperWt * kWtKeys);
-
-  uint4 k[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u64 sb0 = (u64)blockIdx.x * supers_per_mega, sb1 = min(n_super, sb0 + supers_per_mega);
+  // Unconditional loads at a clamped address (what a thread past the end reads is masked out below by
+  // its count of valid values): a load under a branch makes the compiler wait for ALL outstanding loads
+  // at every use, and the rounds ahead would not be in flight.  May overrun the keys by <16 B: data or padding.
+  const u64 koff_last = (keylen - 1) & ~(u64)15;
+  auto load = [&](u64 sb) -> uint4 { return ld_u128(in + min(sb * (kSuperWt * kWtKeys) + 16 * t, koff_last)); };
+  uint4 k[kDirAhead];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u64 koff = key_base + (u64)i * 4096 + 16 * t;
-    k[i] = make_uint4(0, 0, 0, 0);
-    if (koff < keylen) k[i] = ld_u128(in + koff);  // may overrun the keys by <16 B: data or padding
-  }
+  for (int i = 0; i < kDirAhead; ++i) k[i] = load(sb0 + i);
+  u32 base = 0;  // data bytes of the mega tile before the current super tile (wave 0)
+  int buf = 0;
+  // The loop is unrolled kDirAhead times so that every load keeps its own register (rotating the
+  // registers by moves would wait for the loads being moved).
+  for (u64 sbb = sb0; sbb < sb1; sbb += kDirAhead) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u64 koff = key_base + (u64)i * 4096 + 16 * t;
-    const u64 first = koff * 4;
-    u32 nv = first < count ? (u32)min((u64)64, (u64)count - first) : 0u;  // valid values, 0..64
-    const u32 w[4] = {k[i].x, k[i].y, k[i].z, k[i].w};
+  for (int r = 0; r < kDirAhead; ++r) {
+    const u64 sb = sbb + r;
+    if (sb >= sb1) break;  // workgroup-uniform
+    const uint4 cur = k[r];
+    const u64 first = (sb * (kSuperWt * kWtKeys) + 16 * t) * 4;  // first value coded by this thread's 16 keys
+    const u32 nv = first < count ? (u32)min((u64)64, (u64)count - first) : 0u;
+    const u32 w[4] = {cur.x, cur.y, cur.z, cur.w};
     u32 s = 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
       s += word_len<V>(mask_codes(w[d], nvd), nvd);
     }
-    // reduce over the 16 lanes (one DPP row) that share a wave tile
     s = row_scan_incl(s);
-    if ((t & 15) == 15) s_sum[i * 16 + (t >> 4)] = s;
+    k[r] = load(sb + kDirAhead);  // behind the last use of cur: the load lands in the register it frees
+    if ((t & 15) == 15) s_sum[buf][t >> 4] = s;
+    lds_barrier();  // not __syncthreads(): the next rounds' loads stay in flight
+    if (wave == 0) {
+      const u32 x = s_sum[buf][lane];
+      const u32 incl = wave_scan_incl(x, lane);
+      const u64 wt = sb * kSuperWt + lane;
+      if (wt < n_wt) wt_rel[wt] = base + incl - x;
+      base += wave_last(incl);
+    }
+    buf ^= 1;  // the buffer written two rounds on is free: the next round's barrier lies in between
   }
-  __syncthreads();
-  if (t < 64) {
-    const u32 x = s_sum[t];
-    const u32 incl = wave_scan_incl(x, t);
-    const u64 wt = sb * kSuperWt + t;
-    if (wt < n_wt) wt_rel[wt] = incl - x;
-    if (t == 63) super_sum[sb] = incl;
   }
-  __syncthreads();  // s_sum is reused by the next super tile
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_scan_super: exclusive 64-bit scan of the super tile sums by one workgroup.
-// super_off[i] = data bytes before super tile i; super_off[n] = total.
-__global__ __launch_bounds__(1024) void k_scan_super(const u32* __restrict__ super_sum,
-                                                     u64* __restrict__ super_off, u32 n,
-                                                     u64* __restrict__ total_out) {
-  __shared__ u64 s_wave[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const u32 per = (n + 1023) / 1024;
-  const u32 lo = min(n, t * per), hi = min(n, lo + per);
-  u64 mine = 0;
-  for (u32 i = lo; i < hi; ++i) mine += super_sum[i];
-  // wave scan on 64-bit values
-  u64 x = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    u64 y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
-  if (lane == 63) s_wave[wave] = x;
-  __syncthreads();
-  u64 base = 0;
-  for (int w = 0; w < wave; ++w) base += s_wave[w];
-  u64 run = base + x - mine;
-  for (u32 i = lo; i < hi; ++i) {
-    super_off[i] = run;
-    run += super_sum[i];
-  }
-  if (t == 1023) {
-    super_off[n] = run;
-    if (total_out) *total_out = run;
-  }
+  if (t == 0) mega_sum[blockIdx.x] = base;
 }
 
 // ---------------------------------------------------------------------------
@@ -266,7 +242,7 @@ __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, cons
 // cover one advancing stretch of the stream).  On a smaller grid a wave goes on
 // with a grid stride, the next tile's keys and offset prefetched.  No
 // inter-workgroup dependency: data offsets come from the directory built by
-// k_key_sums / k_scan_super.  HBM traffic per value: 0.25 (keys) + dbar (data)
+// k_key_sums.  HBM traffic per value: 0.25 (keys) + dbar (data)
 // + 4 (out).
 // OUT: 0 = the integers; 1 = float32 (int32)value * scale (dequantise fused into the
 // store); 2 = the same added to what out already holds (dequantise-accumulate).
@@ -274,9 +250,7 @@ __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, cons
 template <int V, bool ZZ, bool SHORTCUT, int OUT = 0>
 __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
                                                    u32* __restrict__ out, u32 count,
-                                                   const u64* __restrict__ super_off,
-                                                   const u32* __restrict__ wt_rel,
-                                                   u64* __restrict__ consumed, u32 aux) {
+                                                   Dir dir, u64* __restrict__ consumed, u32 aux) {
   __shared__ WaveLds s_lds[kWaves];
   const int lane = lane_id(), wave = wave_id();
   WaveLds& S = s_lds[wave];
@@ -292,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
     return koff < keylen ? ld_u32(in + koff) : 0u;
   };
   u32 w_next = load_keys(wt);
-  u64 off_next = super_off[wt / kSuperWt] + wt_rel[wt];
+  u64 off_next = dir_offset(dir, wt, lane);
 
   while (true) {
     const u32 w = w_next;
@@ -300,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
     const u32 wt_n = wt + stride;
     if (wt_n < n_wt) {
       w_next = load_keys(wt_n);
-      off_next = super_off[wt_n / kSuperWt] + wt_rel[wt_n];
+      off_next = dir_offset(dir, wt_n, lane);
     }
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);

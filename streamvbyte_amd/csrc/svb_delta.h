@@ -62,8 +62,7 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
 template <int V, bool ZZ, int NW = kWaves>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
-    const u64* __restrict__ super_off, const u32* __restrict__ wt_rel, WsHeader* __restrict__ hdr,
-    LbWords lb, u64* __restrict__ consumed) {
+    Dir dir, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
   __shared__ WaveLds s_lds[NW];
   __shared__ u32 s_wave_tot[NW];
   __shared__ u32 s_prefix;
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     if (wt < n_wt) {
       const u64 koff = (u64)wt * kWtKeys + 4 * lane;
       if (koff < keylen) w[q] = ld_u32(in + koff);
-      doff[q] = super_off[wt / kSuperWt] + wt_rel[wt];
+      doff[q] = dir_offset(dir, wt, lane);
     }
   }
 #pragma unroll
@@ -127,9 +126,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
 // 0.25+dbar+4), which a streaming kernel at two thirds of HBM peak still turns
 // into less time than the look-back version's per-tile hand-off wait.
 template <int V, bool ZZ>
-__global__ __launch_bounds__(kBlock) void k_value_sums(const u8* __restrict__ in, u32 count,
-                                                       const u64* __restrict__ super_off,
-                                                       const u32* __restrict__ wt_rel,
+__global__ __launch_bounds__(kBlock) void k_value_sums(const u8* __restrict__ in, u32 count, Dir dir,
                                                        u32* __restrict__ wt_vsum) {
   __shared__ WaveLds s_lds[kWaves];
   const int lane = lane_id(), wave = wave_id();
@@ -141,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_value_sums(const u8* __restrict__ in
   for (u32 wt = blockIdx.x * kWaves + wave; wt < n_wt; wt += stride) {
     const u64 koff = (u64)wt * kWtKeys + 4 * lane;
     const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
-    const u64 doff = super_off[wt / kSuperWt] + wt_rel[wt];
+    const u64 doff = dir_offset(dir, wt, lane);
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
     uint4 v[4];
@@ -200,9 +197,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32_top(u32* __restrict__ blk, u3
 
 template <int V, bool ZZ>
 __global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__ in,
-                                                          u32* __restrict__ out, u32 count,
-                                                          const u64* __restrict__ super_off,
-                                                          const u32* __restrict__ wt_rel,
+                                                          u32* __restrict__ out, u32 count, Dir dir,
                                                           const u32* __restrict__ wt_vpre,
                                                           const u32* __restrict__ blk_pre,
                                                           u64* __restrict__ consumed) {
@@ -216,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__
   for (u32 wt = blockIdx.x * kWaves + wave; wt < n_wt; wt += stride) {
     const u64 koff = (u64)wt * kWtKeys + 4 * lane;
     const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
-    const u64 doff = super_off[wt / kSuperWt] + wt_rel[wt];
+    const u64 doff = dir_offset(dir, wt, lane);
     u32 run = wt_vpre[wt] + blk_pre[wt >> 10];  // sum of everything before this wave tile, incl. prev
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);

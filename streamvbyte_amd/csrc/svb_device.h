@@ -60,6 +60,15 @@ __device__ __forceinline__ u32 lds_u32_aligned(const u8* base, u32 p) {
   return __builtin_amdgcn_alignbyte(hi, lo, p);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// every outstanding global load of the wave (its fence drains vmcnt), which ends
+// any software pipelining of loads across the barrier; here loads requested
+// before the barrier stay in flight.  Use only where the data handed over at the
+// barrier lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- cross-lane primitives on DPP (no LDS traffic) ------------------------------
 // row_shr:n moves data n lanes up inside each row of 16 lanes (zero shifted in),
 // row_bcast:15 / :31 carry the last lane of a row / of the lower half-wave into
@@ -210,17 +219,19 @@ struct WsHeader {
   u32 error;        // set non-zero when a bounded spin gave up
   u32 ticket;       // dynamic tile counter of the look-back kernels
   u64 accum;        // reduction scratch (validate)
-  u64 total_data;   // total data bytes of the stream being processed
+  u64 reserved;
   u32 pad[58];
 };
 static_assert(sizeof(WsHeader) == 256, "header is one 256-byte block");
 
 struct WsLayout {
   u64 n_wt, n_super, n_tiles;
-  size_t off_super_off, off_wt_rel, off_super_sum, off_status, off_lb_group, off_wt_vsum, off_blk, off_bounds, total;
+  size_t off_mega_sum, off_wt_rel, off_status, off_lb_group, off_wt_vsum, off_blk, off_bounds, total;
+  u32 wt_per_mega, n_mega;
 };
 __host__ __device__ constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kLbWt = 16;  // wave tiles per look-back tile (16384 values)
+constexpr int kMegas = 256;  // mega tiles of the offset directory (at most; one workgroup of k_key_sums each)
 
 __host__ __device__ constexpr WsLayout ws_layout(u32 count) {
   WsLayout L{};
@@ -232,14 +243,39 @@ __host__ __device__ constexpr WsLayout ws_layout(u32 count) {
   // the look-back words follow the header so one memset clears both
   L.off_status = o;    o += align256(8 * (L.n_wt / kWaves + 2));  // room for the smallest tile size
   L.off_lb_group = o;  o += align256(8 * (L.n_wt / kWaves / 16 + 2));  // group words of the two-level look-back
-  L.off_super_off = o; o += align256(8 * (L.n_super + 1));
+  // offset directory: the key block is cut into at most kMegas equal runs of whole super tiles
+  const u64 spm = (L.n_super + kMegas - 1) / kMegas;  // super tiles per mega tile (0 for an empty stream)
+  L.wt_per_mega = (u32)(spm * kSuperWt);
+  L.n_mega = spm ? (u32)((L.n_super + spm - 1) / spm) : 0u;
+  L.off_mega_sum = o;  o += align256(4 * kMegas);
   L.off_wt_rel = o;    o += align256(4 * L.n_wt);
-  L.off_super_sum = o; o += align256(4 * L.n_super);
   L.off_wt_vsum = o;   o += align256(4 * L.n_wt);            // per-wave-tile value sums (delta decode)
   L.off_blk = o;       o += align256(4 * (L.n_wt / 1024 + 2));
   L.off_bounds = o;    o += align256(4 * (L.n_wt / 4 + 2));  // one place in the sorted array per 4 wave tiles (intersection)
   L.total = o;
   return L;
+}
+
+// ---- offset directory ------------------------------------------------------------
+// Two levels, built by k_key_sums in ONE pass over the key block with no
+// communication between workgroups: the key block is cut into n_mega <= 256 runs
+// of wt_per_mega wave tiles; mega_sum[m] = data bytes of run m (at most 64 MiB:
+// a stream holds < 2^32 values), wt_rel[wt] = data bytes between the start of
+// wave tile wt's run and the wave tile.  The bytes before a run are summed where
+// they are needed: 256 sums are one 16-byte load per lane and three DPP
+// reductions, cheaper than a scan kernel of their own (a launch costs ~5 us).
+struct Dir {
+  const u32* mega_sum;  // kMegas entries are readable; those at or beyond n_mega hold anything
+  const u32* wt_rel;
+  u32 wt_per_mega;
+};
+// Data offset of wave tile wt (wave-uniform in, wave-uniform out; every lane takes part).
+__device__ __forceinline__ u64 dir_offset(const Dir& d, u32 wt, int lane) {
+  const u32 m = wt / d.wt_per_mega;
+  const uint4 s = *reinterpret_cast<const uint4*>(d.mega_sum + 4 * lane);
+  const u32 i0 = 4u * lane;
+  const u64 mine = (u64)(i0 < m ? s.x : 0u) + (i0 + 1u < m ? s.y : 0u) + (i0 + 2u < m ? s.z : 0u) + (i0 + 3u < m ? s.w : 0u);
+  return wave_sum64(mine) + d.wt_rel[wt];
 }
 
 }  // namespace svb

@@ -141,8 +141,7 @@ __device__ __forceinline__ u32 valid4(u32 nints, int j, int lane) {
 // ascending still gets the right answer but may walk much of b.
 template <int V>
 __global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
-    const u8* __restrict__ in, u32 count, const u64* __restrict__ super_off,
-    const u32* __restrict__ wt_rel, const u32* __restrict__ wt_vpre, const u32* __restrict__ blk_pre,
+    const u8* __restrict__ in, u32 count, Dir dir, const u32* __restrict__ wt_vpre, const u32* __restrict__ blk_pre,
     const u32* __restrict__ b, u32 n_b, const u32* __restrict__ bound, u32* __restrict__ out,
     u64* __restrict__ n_out, u32 n_tiles, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
   __shared__ WaveLds s_lds[kWaves];
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
     if (wt < n_wt) {
       const u64 koff = (u64)wt * kWtKeys + 4 * lane;
       if (koff < keylen) w[q] = ld_u32(in + koff);
-      doff[q] = super_off[wt / kSuperWt] + wt_rel[wt];
+      doff[q] = dir_offset(dir, wt, lane);
       vpre[q] = wt_vpre[wt] + blk_pre[wt >> 10];
       nints[q] = (u32)min((u64)kWtInts, (u64)count - (u64)wt * kWtInts);
     }

@@ -82,31 +82,57 @@ __global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32
 // last, the final comparison with inLength (src/streamvbyte_decode.c:134-135).
 // *accum must be zero before launch; in_length >= keyLen > 0.
 // Reads 0.25 B per value.
-template <int V>
-__global__ __launch_bounds__(kBlock) void k_validate_sum(const u8* __restrict__ in, u32 count,
-                                                         u64 in_length, u64* __restrict__ accum,
-                                                         u32* __restrict__ ok) {
-  __shared__ u64 s_tmp[kWaves];
+// Workgroups of NT threads; a workgroup's round r takes the 16 NT bytes of keys at piece
+// blockIdx.x + r * gridDim.x, so that at any moment the grid reads one compact window of
+// the key block (contiguous shares per workgroup, 256 KiB apart, all start on the same
+// memory channels and crawl).  At most a few hundred workgroups: their one atomic each
+// lands on the same word, ~12 ns apiece.  kValAhead 16-byte loads in flight per thread.
+constexpr int kValAhead = 6;
+template <int V, int NT = 1024>
+__global__ __launch_bounds__(NT) void k_validate_sum(const u8* __restrict__ in, u32 count,
+                                                     u64 in_length, u64* __restrict__ accum,
+                                                     u32* __restrict__ ok) {
+  __shared__ u64 s_tmp[16];
   const u64 keylen = ((u64)count + 3) >> 2;
-  const u64 nchunks = (keylen + 15) >> 4;
+  const u64 nchunks = (keylen + 15) >> 4;  // 16-byte pieces of the key block
+  // whole pieces in the streaming loop; the last piece of the key block, when it is partial, apart
+  // (byte loads that stay inside the key block: validation may not trust what follows it)
+  const u64 whole = keylen >> 4;
   u64 acc = 0;
-  for (u64 c = (u64)blockIdx.x * kBlock + threadIdx.x; c < nchunks; c += (u64)gridDim.x * kBlock) {
-    const u64 koff = c << 4;
-    uint4 k = make_uint4(0, 0, 0, 0);
-    if (koff + 16 <= keylen) {
-      k = ld_u128(in + koff);
-    } else {  // last chunk: stay inside the key block, validation may not trust what follows
-      u32 w[4] = {0, 0, 0, 0};
-      for (u64 b = koff; b < keylen; ++b) w[(b - koff) >> 2] |= (u32)in[b] << (8 * ((b - koff) & 3));
-      k = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    const u64 first = koff * 4;
-    const u32 nv = (u32)min((u64)64, (u64)count - first);
-    const u32 w[4] = {k.x, k.y, k.z, k.w};
+  auto add_piece = [&](const uint4& p, u64 c) {
+    const u32 nv = (u32)min((u64)64, (u64)count - (c << 6));  // values coded by piece c
+    const u32 w[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
       acc += word_len<V>(mask_codes(w[d], nvd), nvd);
+    }
+  };
+  if (blockIdx.x == 0 && threadIdx.x == 0 && whole < nchunks) {
+    const u64 koff = whole << 4;
+    u32 w[4] = {0, 0, 0, 0};
+    for (u64 b = koff; b < keylen; ++b) w[(b - koff) >> 2] |= (u32)in[b] << (8 * ((b - koff) & 3));
+    add_piece(make_uint4(w[0], w[1], w[2], w[3]), whole);
+  }
+  if (whole) {  // workgroup-uniform
+    // Unconditional loads at a clamped piece index (a load under a branch makes the compiler wait for
+    // ALL outstanding loads at every use); what lies past the end is loaded from the last whole piece
+    // and never added.
+    auto load = [&](u64 c) -> uint4 { return ld_u128(in + (min(c, whole - 1) << 4)); };
+    const u64 stride = (u64)gridDim.x * NT;
+    const u64 first = (u64)blockIdx.x * NT + threadIdx.x;
+    uint4 k[kValAhead];
+#pragma unroll
+    for (int i = 0; i < kValAhead; ++i) k[i] = load(first + stride * i);
+    // unrolled kValAhead times: every load keeps its own register (rotating the registers by moves
+    // would wait for the loads being moved)
+    for (u64 cb = first; cb < whole; cb += stride * kValAhead) {
+#pragma unroll
+      for (int r = 0; r < kValAhead; ++r) {
+        const u64 c = cb + stride * r;
+        if (c < whole) add_piece(k[r], c);
+        k[r] = load(c + stride * kValAhead);  // behind the last use: the load lands in the register it frees
+      }
     }
   }
   const u64 tot = block_sum64(acc, s_tmp);
