@@ -127,9 +127,20 @@ def event_ms(torch, fn, iters, warmup=2):
     return float(np.mean(ms)), float(ms[len(ms) // 2])
 
 
-def cpu_baseline(values_host, threads_all):
-    """The reference library (or, where it was not built, the oracle port) on the
-    host cores: decode of a bounded sample, one thread and all threads."""
+def cpu_share():
+    """CPUs this process may use for the baseline: its affinity set, at most 16 (a one-GPU box is a
+    16-CPU share of a much larger machine: os.cpu_count() there counts CPUs that belong to others)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    return cpus[:16]
+
+
+def cpu_baseline(values_host):
+    """The reference library (or, where it was not built, the oracle port) on the host cores, on the
+    same 2^28-value stream the GPU decodes: one thread, then P equal independent streams on P pinned
+    threads.  Median of 10 runs after a warm-up run, time.perf_counter (CLOCK_MONOTONIC)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle, Reference, max_compressedbytes
     try:
@@ -137,7 +148,6 @@ def cpu_baseline(values_host, threads_all):
     except FileNotFoundError:
         cpu = Oracle()
     n = values_host.size
-    u8p, u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32)
 
     def enc(v, out):
         return cpu._encode(0, v, v.size, out, False, 0)
@@ -147,64 +157,80 @@ def cpu_baseline(values_host, threads_all):
 
     comp = np.zeros(max_compressedbytes(n), dtype=np.uint8)
     size = enc(values_host, comp)
-    back = np.empty(n, dtype=np.uint32)
+    back = np.zeros(n, dtype=np.uint32)
     dec(comp, back, n)
     assert np.array_equal(back, values_host)
 
-    def best_of(f, reps):
-        best = 1e30
+    def median_of(f, reps, warm=1):
+        for _ in range(warm):
+            f()
+        ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
             f()
-            best = min(best, time.perf_counter() - t0)
-        return best
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), float(min(ts))
 
-    reps = 5
-    t_dec = best_of(lambda: dec(comp, back, n), reps)
-    t_enc = best_of(lambda: enc(values_host, comp), reps)
+    reps = 10
+    t_dec, t_dec_best = median_of(lambda: dec(comp, back, n), reps)
+    t_enc, t_enc_best = median_of(lambda: enc(values_host, comp), reps)
 
-    # all cores: P equal independent streams, one thread each (ctypes drops the GIL)
-    P = threads_all
+    # all cores: P equal independent streams, one pinned thread each (ctypes drops the GIL)
+    cpus = cpu_share()
+    P = len(cpus)
     per = n // P
     parts = [np.ascontiguousarray(values_host[i * per:(i + 1) * per]) for i in range(P)]
     comps = [np.zeros(max_compressedbytes(per), dtype=np.uint8) for _ in range(P)]
-    outs = [np.empty(per, dtype=np.uint32) for _ in range(P)]
+    outs = [np.zeros(per, dtype=np.uint32) for _ in range(P)]
     for i in range(P):
         enc(parts[i], comps[i])
 
     def run_all(job):
-        ths = [threading.Thread(target=job, args=(i,)) for i in range(P)]
+        def pinned(i):
+            try:
+                os.sched_setaffinity(0, {cpus[i]})  # the calling thread only
+            except (AttributeError, OSError):
+                pass
+            job(i)
+        ths = [threading.Thread(target=pinned, args=(i,)) for i in range(P)]
         for t in ths:
             t.start()
         for t in ths:
             t.join()
 
-    t_dec_all = best_of(lambda: run_all(lambda i: dec(comps[i], outs[i], per)), 3)
-    t_enc_all = best_of(lambda: run_all(lambda i: enc(parts[i], comps[i])), 3)
-    # the reference's own benchmark shape (tests/perf.c:52-53 there): 500 000 values
-    # v = r31 >> (s & 31), cache-resident, best of 100 trials
+    t_dec_all, _ = median_of(lambda: run_all(lambda i: dec(comps[i], outs[i], per)), reps)
+    t_enc_all, _ = median_of(lambda: run_all(lambda i: enc(parts[i], comps[i])), reps)
+    # the reference's own benchmark shape (tests/perf.c:52-75 there): 500 000 values
+    # v = r31 >> (s & 31), cache-resident, 100 trials of encode then 100 of decode, equality check
     rng = np.random.default_rng(1)
     c1 = (rng.integers(0, 1 << 31, size=500000, dtype=np.uint64) >> (rng.integers(0, 1 << 31, size=500000, dtype=np.uint64) & 31)).astype(np.uint32)
     c1_comp = np.zeros(max_compressedbytes(c1.size), dtype=np.uint8)
     c1_size = enc(c1, c1_comp)
-    c1_back = np.empty(c1.size, dtype=np.uint32)
-    t_c1_dec = best_of(lambda: dec(c1_comp, c1_back, c1.size), 100)
-    t_c1_enc = best_of(lambda: enc(c1, c1_comp), 100)
+    c1_back = np.zeros(c1.size, dtype=np.uint32)
+    t_c1_enc, _ = median_of(lambda: enc(c1, c1_comp), 100)
+    t_c1_dec, _ = median_of(lambda: dec(c1_comp, c1_back, c1.size), 100)
     assert np.array_equal(c1_back, c1)
     gb = 4.0 * n / 1e9
+    dbar = (size - (n + 3) // 4) / n
     return {
+        "value": round(gb / t_dec, 3), "unit": "GB/s (uint32 out, decode)", "cores": 1, "kind": cpu.kind,
+        "sample": f"the whole 2^{int(np.log2(n))}-value stream of the workload ({size} B, DRAM-resident), "
+                  f"median of {reps} runs after a warm-up run",
+        "decode_Gints_per_s": round(n / t_dec / 1e9, 3), "decode_best_GBps": round(gb / t_dec_best, 3),
+        "decode_algorithmic_GBps": round((4.25 + dbar) * n / t_dec / 1e9, 3),
+        "encode_GBps": round(gb / t_enc, 3), "encode_Gints_per_s": round(n / t_enc / 1e9, 3),
+        "all_cores": {"cores": P, "cores_visible": os.cpu_count(), "pinned": True,
+                      "decode_GBps": round(4.0 * per * P / 1e9 / t_dec_all, 3),
+                      "decode_Gints_per_s": round(per * P / 1e9 / t_dec_all, 3),
+                      "encode_GBps": round(4.0 * per * P / 1e9 / t_enc_all, 3),
+                      "note": f"{P} equal independent streams of 2^{int(np.log2(per))} values, one pinned thread each; "
+                              "P = this process's CPU affinity, at most the 16-CPU share of a one-GPU box"},
         "perf_c_500k": {"decode_GBps": round(4.0 * c1.size / 1e9 / t_c1_dec, 3),
                         "encode_GBps": round(4.0 * c1.size / 1e9 / t_c1_enc, 3),
+                        "decode_Gints_per_s": round(c1.size / 1e9 / t_c1_dec, 3),
+                        "encode_Gints_per_s": round(c1.size / 1e9 / t_c1_enc, 3),
                         "stream_bytes": int(c1_size), "cores": 1,
-                        "note": "500 000 values r31 >> (s & 31), cache-resident, best of 100"},
-        "value": round(gb / t_dec, 3), "unit": "GB/s (uint32 out, decode)", "cores": 1, "kind": cpu.kind,
-        "sample": f"first 2^{int(np.log2(n))} values of the workload, best of {reps}, DRAM-resident "
-                  f"({size} B stream)",
-        "decode_Gints_per_s": round(n / t_dec / 1e9, 3),
-        "encode_GBps": round(gb / t_enc, 3),
-        "all_cores": {"cores": P, "decode_GBps": round(4.0 * per * P / 1e9 / t_dec_all, 3),
-                      "encode_GBps": round(4.0 * per * P / 1e9 / t_enc_all, 3),
-                      "note": f"{P} equal independent streams, one thread each"},
+                        "note": "500 000 values r31 >> (s & 31), cache-resident, median of 100 after a warm-up run"},
     }
 
 
@@ -382,6 +408,20 @@ def main():
                      "whole_step_frac": round((alg_bytes + 0.25 * n) / (t / a.steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
+    # ---- measured ceiling: a streaming kernel that moves the same number of bytes -------------
+    # the library's own element-wise map (16-byte loads and stores, a workgroup per chunk like
+    # k_decode, trivial arithmetic) on alg_bytes / 8 values: alg_bytes / 2 read + alg_bytes / 2 written
+    m_copy = int(alg_bytes // 8)
+    cp_src = torch.empty(m_copy, dtype=torch.int32, device=device)
+    cp_dst = torch.empty(m_copy, dtype=torch.int32, device=device)
+    cp_ms, _ = event_ms(torch, lambda: codec.zigzag(cp_src, "decode", out=cp_dst), 10)
+    copy_gbps = 8.0 * m_copy / (cp_ms * 1e-3) / 1e9
+    res["roofline"]["copy_ceiling"] = {"GBps": round(copy_gbps, 1), "of_peak": round(copy_gbps / HBM_PEAK_GBS, 4),
+                                       "kernel": "k_zigzag<decode>: element-wise map, 16 B per lane, same bytes moved",
+                                       "ms": round(cp_ms, 4)}
+    res["roofline"]["frac_of_copy"] = round(achieved / copy_gbps, 4)
+    del cp_src, cp_dst
+
     # ---- encode, same stream --------------------------------------------------
     enc_out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device=device)
     te = time_steps(torch, lambda: codec.encode(values, out=enc_out), max(3, a.steps // 2), 2, dist)
@@ -543,9 +583,8 @@ def main():
         del vals, back, bbuf
 
         if rank == 0 and world == 1:
-            m = min(n, 1 << 26)
-            host = values[:m].cpu().numpy().view(np.uint32).copy()
-            res["cpu_baseline"] = cpu_baseline(host, min(16, os.cpu_count() or 1))
+            host = values.cpu().numpy().view(np.uint32)
+            res["cpu_baseline"] = cpu_baseline(host)
 
     if dist:
         dist.barrier()

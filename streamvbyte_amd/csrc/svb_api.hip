@@ -996,6 +996,15 @@ uint64_t fetch_total_data(Ctx* c, uint32_t count) {
   return total;
 }
 void check_scan(Ctx* c) {
+  if (o_debug.load(std::memory_order_relaxed) & 64u) {
+    // diagnostic only: the status read as it was before the concurrency fix, an asynchronous copy into
+    // a variable on the calling thread's stack (tools/stress_threads.py ... stack)
+    u32 err = 0;
+    HIP_OR_DIE(hipMemcpyAsync(&err, c->ws, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OR_DIE(hipStreamSynchronize(c->stream));
+    if (err) die("device scan", SVBGPU_ESCAN);
+    return;
+  }
   HIP_OR_DIE(hipMemcpyAsync(c->h_res + 2, c->ws, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_OR_DIE(hipStreamSynchronize(c->stream));
   if (reinterpret_cast<const uint32_t*>(c->h_res + 2)[0]) die("device scan", SVBGPU_ESCAN);

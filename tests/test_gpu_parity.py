@@ -510,3 +510,43 @@ def test_validate_batch(torch_mod, codec, oracle, variant):
     got = codec.validate_batch(torch.from_numpy(buf).cuda(), torch.from_numpy(off[:-1].copy()).cuda(),
                                torch.from_numpy(lengths).cuda(), to_dev(torch, counts), variant=variant)
     assert np.array_equal(got.cpu().numpy(), expect), np.flatnonzero(got.cpu().numpy() != expect)
+
+
+def test_device_api_from_concurrent_threads(torch_mod, oracle):
+    """The device-pointer API keeps no state outside what the caller passes in: eight threads, each with
+    its own workspace, result words and HIP stream, encode and decode at once and get the oracle's bytes.
+    (No lock inside the library covers these calls.)"""
+    import threading
+    import streamvbyte_amd as svb
+    torch = torch_mod
+    errors = []
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(700 + t)
+            codec = svb.DeviceCodec(max_count=1 << 21)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for i in range(10):
+                    n = int(rng.integers(1, 1 << 21))
+                    variant = (t + i) & 1
+                    flags = svb.DELTA if (i % 3 == 0) else 0
+                    v = GENERATORS[["width_mix", "postings", "perf_c", "sparse"][(t + i) % 4]](rng, n)
+                    expect = oracle.encode(variant, v, bool(flags), t)
+                    d_v = to_dev(torch, v)
+                    out, size = codec.encode(d_v, variant=variant, flags=flags, prev=t)
+                    back, used = codec.decode(out, n, variant=variant, flags=flags, prev=t)
+                    stream.synchronize()
+                    codec.check()
+                    assert int(size.item()) == expect.size == int(used.item()), (t, i)
+                    assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (t, i)
+                    assert np.array_equal(to_np(back, np.uint32), v), (t, i)
+        except BaseException as exc:  # noqa: BLE001 - reported by the main thread
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]

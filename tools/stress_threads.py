@@ -15,6 +15,15 @@ from util import GENERATORS
 oracle = Oracle()
 T, ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 40
 what = sys.argv[3] if len(sys.argv) > 3 else "all"
+serialize = int(sys.argv[4]) if len(sys.argv) > 4 else 1   # one host-pointer call at a time per device
+stage = int(sys.argv[5]) if len(sys.argv) > 5 else 1       # pageable memory through page-locked chunks
+L = svb.load()
+assert L.svbgpu_set_option(b"host_cpu_cutoff", 0) == 0     # every call to the GPU, whatever its size
+assert L.svbgpu_set_option(b"host_serialize", serialize) == 0
+assert L.svbgpu_set_option(b"host_stage_pageable", stage) == 0
+stack_status = len(sys.argv) > 6 and sys.argv[6] == "stack"  # look-back status copied into a stack variable (as before the fix)
+assert L.svbgpu_set_option(b"debug_ablate", 64 if stack_status else 0) == 0
+print(f"threads {T} iters {ITERS} what {what} serialize {serialize} stage_pageable {stage} stack_status {stack_status}", flush=True)
 errors = []
 
 def worker(t):
