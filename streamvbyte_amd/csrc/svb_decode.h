@@ -84,10 +84,30 @@ struct __align__(16) WaveLds {
 
 // Blocked phase: lane holds keys 4l..4l+3 in w.  Writes the 4 entries of those
 // keys and returns the wave tile's data byte count.
+// A/B build only (-DSVB_LENGTH_TABLE_LDS, tools/ab_length_table.sh): the reference's 256-entry
+// length table (src/streamvbyte_shuffle_tables_decode.h:5-22, _0124_decode.h:2-19 there) resident in
+// LDS, one byte per key, filled by k_decode's 256 threads at kernel start.  The product evaluates the
+// same table arithmetically, four keys per instruction (key_lens4); the measurement that decided it is
+// recorded with the kernel's description.
 template <int V>
+__device__ __forceinline__ u8* lds_len_table() {
+  __shared__ u8 tab[256];
+  return tab;
+}
+template <int V>
+__device__ __forceinline__ u32 key_lens4_table(u32 w_masked, u32 nv) {
+  const u8* tab = lds_len_table<V>();
+  u32 L = (u32)tab[w_masked & 0xFFu] | ((u32)tab[(w_masked >> 8) & 0xFFu] << 8) |
+          ((u32)tab[(w_masked >> 16) & 0xFFu] << 16) | ((u32)tab[w_masked >> 24] << 24);
+  // the table counts four values per key; a 1234 key with absent values counts one byte each too many
+  if (V == V1234) L -= 0x04040404u - valid_per_key4(nv);
+  return L;
+}
+
+template <int V, bool TABLE = false>
 __device__ __forceinline__ u32 scan_keys_to_entries(u32 w, u32 nv, int lane, u32* ent) {
   w = mask_codes(w, nv);
-  const u32 L = key_lens4<V>(w, nv);                 // 4 packed lengths
+  const u32 L = TABLE ? key_lens4_table<V>(w, nv) : key_lens4<V>(w, nv);  // 4 packed lengths
   const u32 tot = (L * 0x01010101u) >> 24;            // their sum (<= 64)
   const u32 P = L * 0x01010100u;                      // packed exclusive prefix inside the lane
   const u32 incl = wave_scan_incl(tot, lane);
@@ -148,7 +168,7 @@ __device__ __forceinline__ uint4 extract_group(u32 entry, u32 shift, const u8* s
 // One wave tile, keys -> values: lane ends up with the (up to) 4 groups
 // j*64+lane, j = 0..3, of the wave tile whose keys it holds blocked in `w`.
 // Values past `nints` are returned as zero.  Returns the tile's data bytes.
-template <int V, bool ZZ, bool SHORTCUT = true>
+template <int V, bool ZZ, bool SHORTCUT = true, bool TABLE = false>
 __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, int lane, WaveLds& S,
                                                uint4 (&v)[4]) {
   // A full wave tile whose 256 keys are all zero (every value below 256; dense
@@ -170,7 +190,7 @@ __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, i
     return V == V1234 ? (u32)kWtInts : 0u;
   }
   const u32 nv = nints > 16u * lane ? min(nints - 16u * lane, 16u) : 0u;
-  const u32 total = scan_keys_to_entries<V>(w, nv, lane, S.ent);
+  const u32 total = scan_keys_to_entries<V, TABLE>(w, nv, lane, S.ent);
   const u32 shift = stage_span(dp, total, lane, S.data);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -254,6 +274,19 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
   __shared__ WaveLds s_lds[kWaves];
   const int lane = lane_id(), wave = wave_id();
   WaveLds& S = s_lds[wave];
+#ifdef SVB_LENGTH_TABLE_LDS
+  constexpr bool kTable = true;
+  {
+    const u32 key = threadIdx.x;  // kBlock == 256: one table entry per thread
+    u32 len = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) len += len_of<V>((key >> (2 * k)) & 3u);
+    lds_len_table<V>()[key] = (u8)len;
+    __syncthreads();
+  }
+#else
+  constexpr bool kTable = false;
+#endif
   const u64 keylen = ((u64)count + 3) >> 2;
   const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
   const u32 stride = gridDim.x * kWaves;
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
     uint4 v[4];
-    const u32 total = decode_wavetile<V, ZZ, SHORTCUT>(w, nints, data_base + doff, lane, S, v);
+    const u32 total = decode_wavetile<V, ZZ, SHORTCUT, kTable>(w, nints, data_base + doff, lane, S, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u64 first = int0 + 4u * (j * 64 + lane);
