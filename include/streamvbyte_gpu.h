@@ -29,6 +29,9 @@ extern "C" {
 #define SVBGPU_1234 0 /* code c -> c+1 data bytes        (streamvbyte_encode)      */
 #define SVBGPU_0124 1 /* code c -> (1<<c)>>1 data bytes   (streamvbyte_encode_0124) */
 
+#define SVBGPU_1248 2 /* 64-bit values, code c -> 1 << c data bytes: svbgpu_encode64 /
+                         svbgpu_decode64 and svbgpu_validate only                    */
+
 #define SVBGPU_DELTA 1u  /* differential coding, uint32 wrap-around, seeded with prev */
 #define SVBGPU_ZIGZAG 2u /* encode: values are int32, zigzag-mapped before coding;
                             decode: un-zigzag after decoding (fuses zigzag_encode/
@@ -206,6 +209,27 @@ int svbgpu_decode_intersect(int variant, const uint8_t *d_in, uint32_t count, ui
                             const uint32_t *d_sorted, uint32_t n_sorted, uint32_t *d_out,
                             uint64_t *d_n_out, void *d_workspace, size_t workspace_bytes,
                             uint64_t *d_consumed, void *stream);
+
+/*
+ * 64-bit values ("1248").  No counterpart in the reference, whose values are
+ * uint32_t (include/streamvbyte.h:23 there); the container is the reference's:
+ * (count + 3) / 4 control bytes, then the data bytes; four 2-bit codes per
+ * control byte, value i of a group in bits 2i..2i+1, unused slots of the last
+ * control byte 0 and without data.  Code c stands for 1 << c little-endian
+ * data bytes (1, 2, 4, 8) -- the smallest of these that holds the value.
+ * Encoder output holds svbgpu_max_compressedbytes64(count) bytes; decoder input
+ * is readable SVBGPU_PADDING64 bytes past the stream.  Workspace as for the
+ * 32-bit calls (svbgpu_workspace_bytes(count)).  svbgpu_validate(SVBGPU_1248, ..)
+ * checks such a stream's control bytes against its length.
+ */
+#define SVBGPU_PADDING64 32
+static inline size_t svbgpu_max_compressedbytes64(uint32_t count) {
+  return ((size_t)count + 3) / 4 + 8 * (size_t)count + SVBGPU_PADDING64;
+}
+int svbgpu_encode64(const uint64_t *d_in, uint32_t count, uint8_t *d_out, void *d_workspace,
+                    size_t workspace_bytes, uint64_t *d_written, void *stream);
+int svbgpu_decode64(const uint8_t *d_in, uint64_t *d_out, uint32_t count, void *d_workspace,
+                    size_t workspace_bytes, uint64_t *d_consumed, void *stream);
 
 /*
  * Batched entry points: `nstreams` independent streams in one launch (posting

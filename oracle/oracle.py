@@ -63,6 +63,11 @@ class Oracle(_Base):
         L.svbo_compressedbytes.argtypes = [C.c_int, _u32p, C.c_uint32]
         L.svbo_validate.restype = C.c_int
         L.svbo_validate.argtypes = [C.c_int, _u8p, C.c_size_t, C.c_uint32]
+        _u64p = C.POINTER(C.c_uint64)
+        L.svbo_encode64.restype = C.c_size_t
+        L.svbo_encode64.argtypes = [_u64p, C.c_uint32, _u8p]
+        L.svbo_decode64.restype = C.c_size_t
+        L.svbo_decode64.argtypes = [_u8p, _u64p, C.c_uint32]
         for nm, a, b in (("svbo_zigzag_encode", _i32p, _u32p), ("svbo_zigzag_decode", _u32p, _i32p)):
             getattr(L, nm).restype = None
             getattr(L, nm).argtypes = [a, b, C.c_size_t]
@@ -76,6 +81,21 @@ class Oracle(_Base):
 
     def _decode(self, variant, stream, out, n, delta, prev):
         return self.lib.svbo_decode(variant, _p(stream, _u8p), _p(out, _u32p), n, int(delta), prev)
+
+    def encode64(self, values):
+        """64-bit values, 1248 variant (no reference counterpart: parity unpinned)"""
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        out = np.zeros((values.size + 3) // 4 + 8 * values.size + 32, dtype=np.uint8)
+        size = self.lib.svbo_encode64(_p(values, C.POINTER(C.c_uint64)), values.size, _p(out, _u8p))
+        return out[:size].copy()
+
+    def decode64(self, stream, n):
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        padded = np.zeros(stream.size + 32, dtype=np.uint8)
+        padded[: stream.size] = stream
+        out = np.zeros(n, dtype=np.uint64)
+        used = self.lib.svbo_decode64(_p(padded, _u8p), _p(out, C.POINTER(C.c_uint64)), n)
+        return out, used
 
     def compressedbytes(self, variant, values):
         values = np.ascontiguousarray(values, dtype=np.uint32)

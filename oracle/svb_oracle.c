@@ -153,3 +153,44 @@ void svbo_zigzag_delta_decode(const uint32_t *in, int32_t *out, size_t n, int32_
         out[i] = (int32_t)p;
     }
 }
+
+/* ---- 64-bit values, the "1248" variant ----------------------------------------
+ * No counterpart in the reference (its API is uint32_t only, include/streamvbyte.h:23):
+ * PARITY UNPINNED for these two functions -- there is no reference output to pin them to.
+ * They restate the format rule that include/streamvbyte_gpu.h gives for svbgpu_encode64 /
+ * svbgpu_decode64: the reference's container (control bytes, then data bytes; four 2-bit
+ * codes per control byte, value i in bits 2(i&3)..; unused slots 0 and without data) with
+ * code c meaning 1 << c little-endian data bytes (1, 2, 4, 8), the smallest that hold the
+ * value. */
+static inline uint32_t svbo_code64(uint64_t v) {
+    return (uint32_t)(v > 0xFFull) + (uint32_t)(v > 0xFFFFull) + (uint32_t)(v > 0xFFFFFFFFull);
+}
+
+size_t svbo_encode64(const uint64_t *in, uint32_t n, uint8_t *out) {
+    if (n == 0) return 0;
+    size_t keylen = ((size_t)n + 3u) / 4u;
+    uint8_t *data = out + keylen;
+    memset(out, 0, keylen);
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t v = in[i];
+        uint32_t c = svbo_code64(v);
+        out[i >> 2] |= (uint8_t)(c << (2u * (i & 3u)));
+        for (uint32_t b = 0; b < (1u << c); b++)
+            *data++ = (uint8_t)(v >> (8u * b));
+    }
+    return (size_t)(data - out);
+}
+
+size_t svbo_decode64(const uint8_t *in, uint64_t *out, uint32_t n) {
+    if (n == 0) return 0;
+    size_t keylen = ((size_t)n + 3u) / 4u;
+    const uint8_t *data = in + keylen;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t c = (in[i >> 2] >> (2u * (i & 3u))) & 3u;
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < (1u << c); b++)
+            v |= (uint64_t)(*data++) << (8u * b);
+        out[i] = v;
+    }
+    return (size_t)(data - in);
+}

@@ -25,6 +25,7 @@
 #include "svb_batch.h"
 #include "svb_lists.h"
 #include "svb_intersect.h"
+#include "svb_wide.h"
 
 using namespace svb;
 
@@ -160,6 +161,8 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   const u32 spm = L.wt_per_mega / kSuperWt;
   if (variant == SVBGPU_1234)
     hipLaunchKernelGGL(k_key_sums<V1234>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
+  else if (variant == SVBGPU_1248)
+    hipLaunchKernelGGL(k_key_sums<V1248>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
   else
     hipLaunchKernelGGL(k_key_sums<V0124>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
   HIP_TRY(hipGetLastError());
@@ -589,7 +592,7 @@ int svbgpu_compressedbytes(int variant, unsigned flags, const uint32_t* d_in, ui
 
 int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32_t count,
                     uint32_t* d_ok, void* ws, size_t ws_bytes, void* stream) {
-  if (bad_variant(variant) || !d_ok) return SVBGPU_EINVAL;
+  if ((bad_variant(variant) && variant != SVBGPU_1248) || !d_ok) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   if (!ws || ws_bytes < sizeof(WsHeader) || ((uintptr_t)ws & 255u)) return SVBGPU_EWORKSPACE;
   const u64 keylen = ((u64)count + 3) >> 2;
@@ -606,6 +609,9 @@ int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32
   const unsigned grid = stream_grid((keylen + 16383) / 16384, 1);
   if (variant == SVBGPU_1234)
     hipLaunchKernelGGL(k_validate_sum<V1234>, dim3(grid), dim3(1024), 0, S(stream), d_in, count,
+                       (u64)in_length, &h->accum, d_ok);
+  else if (variant == SVBGPU_1248)
+    hipLaunchKernelGGL(k_validate_sum<V1248>, dim3(grid), dim3(1024), 0, S(stream), d_in, count,
                        (u64)in_length, &h->accum, d_ok);
   else
     hipLaunchKernelGGL(k_validate_sum<V0124>, dim3(grid), dim3(1024), 0, S(stream), d_in, count,
@@ -712,6 +718,44 @@ int svbgpu_decode_intersect(int variant, const uint8_t* d_in, uint32_t count, ui
     launch_intersect<V1234>(d_in, count, prev, d_sorted, n_sorted, d_out, d_n_out, ws, d_consumed, S(stream));
   else
     launch_intersect<V0124>(d_in, count, prev, d_sorted, n_sorted, d_out, d_n_out, ws, d_consumed, S(stream));
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_encode64(const uint64_t* d_in, uint32_t count, uint8_t* d_out, void* ws, size_t ws_bytes,
+                    uint64_t* d_written, void* stream) {
+  if (count == 0) {
+    if (d_written) { int rc0 = fill_u32(d_written, 0u, 8, S(stream)); if (rc0) return rc0; }
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  const WsLayout L = ws_layout(count);
+  hipLaunchKernelGGL(k_sizes64, dim3(L.n_mega), dim3(1024), 0, S(stream), d_in, count, ws_at<u32>(ws, L.off_wt_rel),
+                     ws_at<u32>(ws, L.off_mega_sum), L.wt_per_mega);
+  hipLaunchKernelGGL(k_encode64, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0, S(stream), d_in, count,
+                     d_out, ws_dir(ws, L), d_written);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_decode64(const uint8_t* d_in, uint64_t* d_out, uint32_t count, void* ws, size_t ws_bytes,
+                    uint64_t* d_consumed, void* stream) {
+  if (count == 0) {
+    if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
+    return SVBGPU_OK;
+  }
+  if (!d_in || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  int rc = check_ws(count, ws, ws_bytes);
+  if (rc) return rc;
+  rc = build_directory(SVBGPU_1248, d_in, count, ws, S(stream));
+  if (rc) return rc;
+  const WsLayout L = ws_layout(count);
+  hipLaunchKernelGGL(k_decode64, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0, S(stream), d_in, d_out,
+                     count, ws_dir(ws, L), d_consumed);
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

@@ -17,6 +17,7 @@ namespace svb {
 
 constexpr int V1234 = 0;
 constexpr int V0124 = 1;
+constexpr int V1248 = 2;  // 64-bit values: code c -> 1 << c data bytes (only the key-block kernels know it)
 
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr int kWaves = 4;
@@ -206,6 +207,10 @@ __device__ __forceinline__ u32 key_lens4(u32 w_masked, u32 nv) {
 template <int V>
 __device__ __forceinline__ u32 word_len(u32 w_masked, u32 nv) {
   u32 lo = __popc(w_masked & 0x55555555u), hi = __popc(w_masked & 0xAAAAAAAAu);
+  if (V == V1248) {  // n0 + 2 n1 + 4 n2 + 8 n3 = nv + n1 + 3 n2 + 7 n3 with n3 = codes with both bits set
+    const u32 n3 = __popc(w_masked & (w_masked >> 1) & 0x55555555u);
+    return nv + (lo - n3) + 3u * (hi - n3) + 7u * n3;
+  }
   if (V == V1234) return nv + lo + 2u * hi;
   return lo + 2u * hi + __popc(w_masked & (w_masked >> 1) & 0x55555555u);
 }

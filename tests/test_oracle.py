@@ -140,3 +140,19 @@ def test_against_compiled_reference(oracle, reference):
         assert np.array_equal(oracle.zigzag_decode(v), reference.zigzag_decode(v))
         assert np.array_equal(oracle.zigzag_delta_encode(sv, p), reference.zigzag_delta_encode(sv, p))
         assert np.array_equal(oracle.zigzag_delta_decode(v, p), reference.zigzag_delta_decode(v, p))
+
+
+def test_wide_1248_rule(oracle):
+    """64-bit values: no reference counterpart (parity unpinned); the oracle against a hand-computed
+    vector of the rule in include/streamvbyte_gpu.h and against itself."""
+    v = np.array([1, 256, 65536, 1 << 32, 5], dtype=np.uint64)
+    s = oracle.encode64(v)
+    assert s.tobytes() == bytes.fromhex("e400" "01" "0001" "00000100" "0000000001000000" "05")
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 3, 4, 5, 1000, 4097):
+        v = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) >> rng.integers(0, 63, size=n).astype(np.uint64)
+        s = oracle.encode64(v)
+        widths = np.where(v > 0xFFFFFFFF, 8, np.where(v > 0xFFFF, 4, np.where(v > 0xFF, 2, 1)))
+        assert s.size == (n + 3) // 4 + int(widths.sum())
+        back, used = oracle.decode64(s, n)
+        assert used == s.size and np.array_equal(back, v)

@@ -128,6 +128,20 @@ if want("misc"):
     ops["zigzag_enc"] = (lambda: codec.zigzag(values, "encode", out=out), 8.0 * n)
     tmpz = torch.empty(n, dtype=torch.int32, device=dev)
     ops["zigzag_delta_dec"] = (lambda: codec.zigzag(values, "delta_decode", out=tmpz), 8.0 * n)
+if want("wide"):
+    n8 = min(n, 1 << 27)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    w8 = torch.randint(0, 4, (n8,), generator=g, device=dev, dtype=torch.int64)
+    r8 = torch.randint(0, 1 << 62, (n8,), generator=g, device=dev, dtype=torch.int64)
+    v8 = r8 >> (62 - torch.minimum(8 << w8, torch.full_like(w8, 62)))   # widths 1, 2, 4, 8 bytes equally likely
+    del w8, r8
+    s8, z8 = codec.encode64(v8)
+    s8 = s8.clone()
+    d8 = (int(z8.item()) - (n8 + 3) // 4) / n8
+    o8 = torch.empty(n8, dtype=torch.int64, device=dev)
+    e8 = torch.empty((n8 + 3) // 4 + 8 * n8 + 32, dtype=torch.uint8, device=dev)
+    ops["encode64"] = (lambda: codec.encode64(v8, out=e8), (8.25 + d8) * n8)
+    ops["decode64"] = (lambda: codec.decode64(s8, n8, out=o8), (8.25 + d8) * n8)
 if want("batch"):
     nl = 1 << 20
     counts, voff, vals = gen_posting_lists(torch, list_lengths(nl, 20241218), 1234, dev)
