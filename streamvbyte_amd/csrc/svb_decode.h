@@ -32,7 +32,10 @@ __global__ __launch_bounds__(1024) void k_key_sums(const u8* __restrict__ in, u3
   // its count of valid values): a load under a branch makes the compiler wait for ALL outstanding loads
   // at every use, and the rounds ahead would not be in flight.  May overrun the keys by <16 B: data or padding.
   const u64 koff_last = (keylen - 1) & ~(u64)15;
-  auto load = [&](u64 sb) -> uint4 { return ld_u128(in + min(sb * (kSuperWt * kWtKeys) + 16 * t, koff_last)); };
+  // (rounds past the mega tile's end re-read its last super tile -- cache hits -- rather than the next one's keys)
+  auto load = [&](u64 sb) -> uint4 {
+    return ld_u128(in + min(min(sb, sb1 - 1) * (kSuperWt * kWtKeys) + 16 * t, koff_last));
+  };
   uint4 k[kDirAhead];
 #pragma unroll
   for (int i = 0; i < kDirAhead; ++i) k[i] = load(sb0 + i);

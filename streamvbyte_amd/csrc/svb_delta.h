@@ -81,6 +81,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
   // keys and offsets of the wave's 4 wave tiles up front
   u32 w[4];
   u64 doff[4];
+  DirWalk walk;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32 wt = wt0 + q;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     if (wt < n_wt) {
       const u64 koff = (u64)wt * kWtKeys + 4 * lane;
       if (koff < keylen) w[q] = ld_u32(in + koff);
-      doff[q] = dir_offset(dir, wt, lane);
+      doff[q] = walk.offset(dir, wt, lane);
     }
   }
 #pragma unroll
@@ -135,10 +136,11 @@ __global__ __launch_bounds__(kBlock) void k_value_sums(const u8* __restrict__ in
   const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
   const u32 stride = gridDim.x * kWaves;
   const u8* data_base = in + keylen;
+  DirWalk walk;
   for (u32 wt = blockIdx.x * kWaves + wave; wt < n_wt; wt += stride) {
     const u64 koff = (u64)wt * kWtKeys + 4 * lane;
     const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
-    const u64 doff = dir_offset(dir, wt, lane);
+    const u64 doff = walk.offset(dir, wt, lane);
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
     uint4 v[4];
@@ -208,10 +210,11 @@ __global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__
   const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
   const u32 stride = gridDim.x * kWaves;
   const u8* data_base = in + keylen;
+  DirWalk walk;
   for (u32 wt = blockIdx.x * kWaves + wave; wt < n_wt; wt += stride) {
     const u64 koff = (u64)wt * kWtKeys + 4 * lane;
     const u32 w = koff < keylen ? ld_u32(in + koff) : 0u;
-    const u64 doff = dir_offset(dir, wt, lane);
+    const u64 doff = walk.offset(dir, wt, lane);
     u32 run = wt_vpre[wt] + blk_pre[wt >> 10];  // sum of everything before this wave tile, incl. prev
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);

@@ -274,13 +274,30 @@ struct Dir {
   const u32* wt_rel;
   u32 wt_per_mega;
 };
-// Data offset of wave tile wt (wave-uniform in, wave-uniform out; every lane takes part).
-__device__ __forceinline__ u64 dir_offset(const Dir& d, u32 wt, int lane) {
-  const u32 m = wt / d.wt_per_mega;
+// Data bytes before mega tile m (wave-uniform in and out; every lane takes part).
+__device__ __forceinline__ u64 dir_mega_base(const Dir& d, u32 m, int lane) {
   const uint4 s = *reinterpret_cast<const uint4*>(d.mega_sum + 4 * lane);
   const u32 i0 = 4u * lane;
   const u64 mine = (u64)(i0 < m ? s.x : 0u) + (i0 + 1u < m ? s.y : 0u) + (i0 + 2u < m ? s.z : 0u) + (i0 + 3u < m ? s.w : 0u);
-  return wave_sum64(mine) + d.wt_rel[wt];
+  return wave_sum64(mine);
 }
+// Data offset of wave tile wt (wave-uniform in, wave-uniform out; every lane takes part).
+__device__ __forceinline__ u64 dir_offset(const Dir& d, u32 wt, int lane) {
+  return dir_mega_base(d, wt / d.wt_per_mega, lane) + d.wt_rel[wt];
+}
+// The same for a wave that walks several wave tiles: the mega tile's base is summed once and
+// again only when the walk crosses into another mega tile.
+struct DirWalk {
+  u32 mega = 0xFFFFFFFFu;
+  u64 base = 0;
+  __device__ __forceinline__ u64 offset(const Dir& d, u32 wt, int lane) {
+    const u32 m = wt / d.wt_per_mega;
+    if (m != mega) {  // wave-uniform
+      mega = m;
+      base = dir_mega_base(d, m, lane);
+    }
+    return base + d.wt_rel[wt];
+  }
+};
 
 }  // namespace svb

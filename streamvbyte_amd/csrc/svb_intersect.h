@@ -164,6 +164,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
   // keys, data offsets and preceding sums of the wave's 4 wave tiles up front
   u32 w[4], vpre[4];
   u64 doff[4];
+  DirWalk walk;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32 wt = wt0 + q;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
     if (wt < n_wt) {
       const u64 koff = (u64)wt * kWtKeys + 4 * lane;
       if (koff < keylen) w[q] = ld_u32(in + koff);
-      doff[q] = dir_offset(dir, wt, lane);
+      doff[q] = walk.offset(dir, wt, lane);
       vpre[q] = wt_vpre[wt] + blk_pre[wt >> 10];
       nints[q] = (u32)min((u64)kWtInts, (u64)count - (u64)wt * kWtInts);
     }
