@@ -6,8 +6,21 @@
  * keeps the reference's signature, return value and byte-exact stream format;
  * the work is done by HIP kernels in libstreamvbyte.so.2.
  *
- * Pointers may be host pointers (the library stages them through device
- * memory) or device pointers from hipMalloc (used in place, no copies).
+ * Pointers may be host pointers or device pointers from hipMalloc.
+ *   - Host pointers: calls of 65 536 values or more are staged through device
+ *     memory and run on the GPU; smaller ones run on the calling thread (SSE4.1 /
+ *     SSSE3 code inside the library, same bytes either way) because two PCIe
+ *     crossings cost more than the work.  The threshold is the option
+ *     "host_cpu_cutoff" of svbgpu_set_option (streamvbyte_gpu.h); 0 sends every
+ *     call to the GPU.  Without a usable gfx950 device the larger calls print a
+ *     message and abort(): this API has no error channel.
+ *   - Device pointers are used in place, no copies, always on the GPU.  The
+ *     kernels run on a stream of the library's own; before they start the
+ *     library waits for everything the caller has queued on the device
+ *     (hipDeviceSynchronize on entry), and the call returns when the result is
+ *     in memory, so a caller needs no synchronisation of its own on either side.
+ *     Callers that want asynchronous calls on their own stream use
+ *     streamvbyte_gpu.h.
  *
  * Stream layout for `length` values: (length+3)/4 control bytes, then the data
  * bytes.  `length` itself is not stored.
@@ -39,7 +52,8 @@ size_t streamvbyte_encode(const uint32_t *in, uint32_t length, uint8_t *out);
 size_t streamvbyte_encode_0124(const uint32_t *in, uint32_t length, uint8_t *out);
 
 /* Worst-case stream size including STREAMVBYTE_PADDING.
- * (same arithmetic as reference include/streamvbyte.h:33-39) */
+ * (the reference's bound, include/streamvbyte.h:33-39 there: control bytes +
+ * four data bytes per value + padding) */
 static inline size_t streamvbyte_max_compressedbytes(const uint32_t length) {
   return ((size_t)length + 3) / 4 + (size_t)length * sizeof(uint32_t) + STREAMVBYTE_PADDING;
 }

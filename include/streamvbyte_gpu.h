@@ -57,13 +57,19 @@ const char *svbgpu_strerror(int code);
 /* 1 when the current HIP device is a gfx950 the library can run on. */
 int svbgpu_device_ok(void);
 
-/* Tuning knobs (process-wide, not thread-safe against running calls):
+/* Tuning knobs.  Each is an atomic word; every API call reads all of them once
+ * on entry and works from that snapshot, so a change never reaches a call that
+ * is already running and may be made from any thread.
+ *   "encode_pipeline" = 0|1     1 (default): plain and zigzag encodes run the
+ *                               software-pipelined kernel (a tile's loads and
+ *                               look-back overlap the previous tile's stores);
+ *                               0: one tile at a time.  Differential encodes
+ *                               always take the latter.
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
- *                               encoder carries through the look-back (default 4)
- *   "encode_waves" = 4 | 8      wavefronts per workgroup of the encoder when
- *                               "encode_tile" is 4 (default 8: a tile of 32 768
- *                               values per look-back; the 0124 encoder always
- *                               uses 4)
+ *                               one-tile-at-a-time encoder carries through the
+ *                               look-back (default 4)
+ *   "encode_waves" = 4 | 8      wavefronts per workgroup of the encoders
+ *                               (default 8; the 0124 encoder always uses 4)
  *   "scan_waves" = 4 | 8 | 16   wavefronts per workgroup of the running sum
  *                               behind svbgpu_zigzag_delta_decode and of the
  *                               single-pass differential decoder (default 16:
@@ -81,10 +87,28 @@ int svbgpu_device_ok(void);
  *                               k > 0: a persistent grid of k workgroups per CU
  *                               with the wave tiles strided over it (slower:
  *                               kept for comparison)
- *   "batch_lists_per_wave" = k  batched calls: a launch gets a workgroup per 4k
- *                               streams, handed out as earlier ones finish
- *                               (default 8); 0: one grid that fills the device,
- *                               streams strided over it
+ *   "batch_chunk" = k           batched calls: -1 (default) every wavefront takes
+ *                               k = 32 (decode) or 8 (encode) consecutive streams,
+ *                               short ones packed a group of four values per lane
+ *                               across stream borders, long ones a wave tile at a
+ *                               time; k in 1..64 sets the number; 0: the older
+ *                               pair of launches (a 16-lane row per short stream,
+ *                               a wavefront per long one)
+ *   "batch_lists_per_wave" = k  only with "batch_chunk" 0: a workgroup per 4k
+ *                               streams (default 8); 0: one grid that fills the
+ *                               device, streams strided over it
+ *   "host_cpu_cutoff" = n       host-pointer calls of the reference-named
+ *                               functions with fewer than n values (default
+ *                               65 536) run on the calling thread (SSE4.1 / SSSE3
+ *                               code in the library) instead of crossing PCIe;
+ *                               0: always the GPU.  Never applies to device
+ *                               pointers.
+ *   "host_serialize" = 0|1      1 (default): host-pointer and frame calls on one
+ *                               device take turns (a mutex per device); 0: they
+ *                               run concurrently, each on its own context
+ *   "host_stage_pageable" = 0|1 1 (default): pageable caller memory moves through
+ *                               the library's page-locked chunks; 0: it is handed
+ *                               to hipMemcpyAsync directly
  *   "zigzag_piece" = n          values per device scan of the host-pointer
  *                               zigzag_delta_decode (default 2^31; longer arrays
  *                               go in pieces)

@@ -189,6 +189,39 @@ def test_device_pointers_through_reference_names(svb, oracle):
     assert used == size and np.array_equal(d_back.cpu().numpy().view(np.uint32), v)
 
 
+def test_device_pointer_calls_wait_for_the_callers_stream(svb, oracle):
+    """The reference-named functions run on a stream of the library's own; with
+    device pointers they first wait for whatever the caller queued on the device.
+    The input is still being produced (a chain of passes over a large tensor on
+    torch's stream) and the output is still being overwritten when the calls are
+    made, and no synchronisation is done here."""
+    import torch
+    lib = svb.load()
+    n = 1 << 24
+    rng = np.random.default_rng(11)
+    v = (rng.integers(0, 2**32, n, dtype=np.uint64) >> rng.integers(0, 32, n).astype(np.uint64)).astype(np.uint32)
+    expect = oracle.encode(0, v)
+    base = torch.from_numpy(v.view(np.int32)).cuda()
+    d_out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device="cuda:0")
+    d_back = torch.empty_like(base)
+    torch.cuda.synchronize()
+    d_v = base ^ 0x5A5A5A5A
+    for _ in range(20):  # ~20 passes over 64 MiB still queued when the encoder is called
+        d_v = d_v ^ 0x0F0F0F0F
+        d_v = d_v ^ 0x0F0F0F0F
+    d_v = d_v ^ 0x5A5A5A5A
+    for _ in range(20):
+        d_out.fill_(0xEE)
+    size = lib.streamvbyte_encode(d_v.data_ptr(), n, d_out.data_ptr())
+    assert size == expect.size
+    for _ in range(20):
+        d_back.fill_(-1)
+    used = lib.streamvbyte_decode(d_out.data_ptr(), d_back.data_ptr(), n)
+    assert used == size
+    assert np.array_equal(d_out[:size].cpu().numpy(), expect)
+    assert np.array_equal(d_back.cpu().numpy().view(np.uint32), v)
+
+
 def test_concurrent_callers(svb, oracle):
     """The reference API is re-entrant (pure functions of their arguments): eight
     threads calling every host-pointer function at once on their own buffers get
