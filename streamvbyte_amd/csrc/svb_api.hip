@@ -604,7 +604,6 @@ int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32
   if (!d_in) return SVBGPU_EINVAL;
   WsHeader* h = ws_hdr(ws);
   { int rc0 = fill_u32(&h->accum, 0u, 8, S(stream)); if (rc0) return rc0; }
-  // a workgroup per CU at most; at least 16 KiB of keys (one load per thread) each
   // a workgroup of 1024 threads per CU at most, at least 16 KiB of keys (one load per thread) each
   const unsigned grid = stream_grid((keylen + 16383) / 16384, 1);
   if (variant == SVBGPU_1234)

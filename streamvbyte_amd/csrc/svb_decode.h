@@ -4,75 +4,140 @@
 // (src/streamvbyte_x64_decode.c:10-26,39-112; scalar src/streamvbyte_decode.c:18-60;
 // 0124 twin src/streamvbyte_0124_decode.c:17-27,38-79,83-157) with prefix sums.
 #pragma once
+#include <type_traits>
 #include "svb_device.h"
 
 namespace svb {
 
 // ---------------------------------------------------------------------------
 // k_key_sums: the offset directory (see Dir) in one pass, one workgroup of 1024
-// threads per mega tile.  A round takes one super tile (16 KiB of keys = 64 wave
-// tiles): thread t reads the 16 keys at 16 t, so every 16 lanes cover one wave
-// tile and a row reduction gives its data bytes; wave 0 scans the 64 sums behind
-// the running offset of the mega tile while the other waves are already in the
-// next round (the sums are double-buffered, one barrier per round).  The loads of
-// the next kDirAhead rounds are in flight.  Reads 0.25 B per value, writes 4 B
-// per 1024 values; no scan kernel behind it, no atomics, nothing to clear.
-constexpr int kDirAhead = 6;
+// threads per mega tile.  A round takes 16 super tiles, one per wave: a wave reads
+// its super tile (16 KiB of keys = 64 wave tiles) with sixteen 16-byte loads per
+// lane, all in flight at once and consumed in the order they land; in load i every
+// row of 16 lanes covers one wave tile (number 4 i + row).  A lane's 16 keys of a
+// load cost three population counts per dword (dir_counts); the 16 per-load sums
+// of a lane are then added up across the row AND dealt out one per lane in the
+// same 15 DPP steps (row_reduce_scatter16), one trip through the wave's own LDS
+// words puts the 64 tile sums in tile order, and a wave scan places the tiles
+// inside the super tile.  The waves meet once per round, to learn what the super
+// tiles before theirs add up to.  When the mega tile has another round, every load
+// register is refilled right after its last use, so the memory pipe stays full
+// across the barrier (which waits for LDS only).  Reads 0.25 B per value, writes
+// 4 B per 1024 values; no scan kernel behind it, no atomics, nothing to clear.
+constexpr int kDirLoads = 16;  // 16-byte loads per lane and super tile
+
+// v[i], i = 0..15: a value per lane.  Returns, in lane p of every row of 16 lanes, the sum over the
+// row of v[dir_dealt(p)]: each halving step keeps one half of the values, hands the other half to the
+// partner lane and adds what the partner hands over (15 DPP adds instead of 16 x 4).
+__device__ __forceinline__ u32 dir_dealt(u32 p) {  // which v a lane ends up with
+  return 8u * (p >> 3) + 4u * ((p >> 2) & 1u) + 2u * (p & 1u) + ((p >> 1) & 1u);
+}
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_get(u32 x) {
+  return (u32)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ u32 row_reduce_scatter16(const u32 (&v)[16], int lane) {
+  const bool h1 = lane & 8, h2 = lane & 4, h3 = lane & 1, h4 = lane & 2;
+  u32 k8[8], k4[4], k2[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k8[j] = (h1 ? v[j + 8] : v[j]) + dpp_get<0x140>(h1 ? v[j] : v[j + 8]);  // row_mirror
+#pragma unroll
+  for (int j = 0; j < 4; ++j) k4[j] = (h2 ? k8[j + 4] : k8[j]) + dpp_get<0x141>(h2 ? k8[j] : k8[j + 4]);  // row_half_mirror
+#pragma unroll
+  for (int j = 0; j < 2; ++j) k2[j] = (h3 ? k4[j + 2] : k4[j]) + dpp_get<0xB1>(h3 ? k4[j] : k4[j + 2]);  // quad_perm [1,0,3,2]
+  return (h4 ? k2[1] : k2[0]) + dpp_get<0x4E>(h4 ? k2[0] : k2[1]);  // quad_perm [2,3,0,1]
+}
+
 template <int V>
 __global__ __launch_bounds__(1024) void k_key_sums(const u8* __restrict__ in, u32 count,
                                                    u32* __restrict__ wt_rel, u32* __restrict__ mega_sum,
                                                    u32 supers_per_mega) {
-  __shared__ u32 s_sum[2][kSuperWt];
+  constexpr int kW = 16;  // waves per workgroup
+  __shared__ u32 s_turn[kW][kSuperWt];
+  __shared__ u32 s_tot[2][kW];
   const u64 keylen = ((u64)count + 3) >> 2;
   const u64 n_wt = (keylen + kWtKeys - 1) / kWtKeys;
   const u64 n_super = (n_wt + kSuperWt - 1) / kSuperWt;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // in a scalar register: branches on it are scalar
   const u64 sb0 = (u64)blockIdx.x * supers_per_mega, sb1 = min(n_super, sb0 + supers_per_mega);
-  // Unconditional loads at a clamped address (what a thread past the end reads is masked out below by
-  // its count of valid values): a load under a branch makes the compiler wait for ALL outstanding loads
-  // at every use, and the rounds ahead would not be in flight.  May overrun the keys by <16 B: data or padding.
+  constexpr u64 kSuperKeys = (u64)kSuperWt * kWtKeys;  // 16 KiB
+  // Loads are unconditional, at a clamped address (what a lane past the end reads is masked out by its
+  // count of valid values): a load under a divergent branch makes the compiler wait for ALL outstanding
+  // loads at every use.  May overrun the keys by <16 B: data or padding.  A wave without a super tile in
+  // this round re-reads the mega tile's last one (cache hits) rather than another workgroup's keys.
+  // (All of it scalar but the lane's 32-bit offset inside the super tile.)
   const u64 koff_last = (keylen - 1) & ~(u64)15;
-  // (rounds past the mega tile's end re-read its last super tile -- cache hits -- rather than the next one's keys)
-  auto load = [&](u64 sb) -> uint4 {
-    return ld_u128(in + min(min(sb, sb1 - 1) * (kSuperWt * kWtKeys) + 16 * t, koff_last));
+  auto load = [&](u64 sb, int i) -> uint4 {
+    const u64 base = min(sb, sb1 - 1) * kSuperKeys;                     // <= koff_last: that super tile exists
+    const u32 room = (u32)min(koff_last - base, (u64)kSuperKeys);        // largest offset that may be read
+    return ld_u128(in + base + min((u32)(1024 * i + 16 * lane), room));
   };
-  uint4 k[kDirAhead];
+  uint4 k[kDirLoads];
+  if (sb0 + wave < sb1) {  // scalar: a short stream leaves most waves of its few workgroups without work
 #pragma unroll
-  for (int i = 0; i < kDirAhead; ++i) k[i] = load(sb0 + i);
-  u32 base = 0;  // data bytes of the mega tile before the current super tile (wave 0)
+    for (int i = 0; i < kDirLoads; ++i) k[i] = load(sb0 + wave, i);
+  }
+  u32 carry = 0;  // data bytes of the mega tile before the current round
   int buf = 0;
-  // The loop is unrolled kDirAhead times so that every load keeps its own register (rotating the
-  // registers by moves would wait for the loads being moved).
-  for (u64 sbb = sb0; sbb < sb1; sbb += kDirAhead) {
+  // One round; MORE: the mega tile has another one, whose keys are requested as registers fall free.
+  auto round = [&](u64 sbb, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const u64 sb = sbb + wave;
+    u32 v[kDirLoads];
+    if (sb >= sb1) {  // scalar: no super tile for this wave in this round (and then in no later one)
 #pragma unroll
-  for (int r = 0; r < kDirAhead; ++r) {
-    const u64 sb = sbb + r;
-    if (sb >= sb1) break;  // workgroup-uniform
-    const uint4 cur = k[r];
-    const u64 first = (sb * (kSuperWt * kWtKeys) + 16 * t) * 4;  // first value coded by this thread's 16 keys
-    const u32 nv = first < count ? (u32)min((u64)64, (u64)count - first) : 0u;
-    const u32 w[4] = {cur.x, cur.y, cur.z, cur.w};
-    u32 s = 0;
+      for (int i = 0; i < kDirLoads; ++i) v[i] = 0;
+    } else if ((sb + 1) * (kSuperKeys * 4) <= (u64)count) {  // scalar: the wave's super tile lacks no value
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
-      s += word_len<V>(mask_codes(w[d], nvd), nvd);
+      for (int i = 0; i < kDirLoads; ++i) {
+        v[i] = dir_counts<V>(k[i]);
+        if (MORE) k[i] = load(sb + kW, i);
+      }
+    } else {
+      // values of the stream from the super tile's first on, at most a super tile's worth (scalar)
+      const u64 sfirst = sb * (kSuperKeys * 4);
+      const int have = sfirst < count ? (int)min((u64)count - sfirst, kSuperKeys * 4) : 0;
+#pragma unroll
+      for (int i = 0; i < kDirLoads; ++i) {
+        const u32 nv = (u32)min(max(have - (4096 * i + 64 * lane), 0), 64);  // of this lane's 16 keys
+        const u32 w[4] = {k[i].x, k[i].y, k[i].z, k[i].w};
+        u32 s = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const u32 nvd = nv > 16u * d ? min(nv - 16u * d, 16u) : 0u;
+          s += word_len<V>(mask_codes(w[d], nvd), nvd);
+        }
+        v[i] = s;
+        if (MORE) k[i] = load(sb + kW, i);
+      }
     }
-    s = row_scan_incl(s);
-    k[r] = load(sb + kDirAhead);  // behind the last use of cur: the load lands in the register it frees
-    if ((t & 15) == 15) s_sum[buf][t >> 4] = s;
-    lds_barrier();  // not __syncthreads(): the next rounds' loads stay in flight
-    if (wave == 0) {
-      const u32 x = s_sum[buf][lane];
-      const u32 incl = wave_scan_incl(x, lane);
-      const u64 wt = sb * kSuperWt + lane;
-      if (wt < n_wt) wt_rel[wt] = base + incl - x;
-      base += wave_last(incl);
+    const u32 mine = row_reduce_scatter16(v, lane);
+    // lane l holds wave tile 4 * dir_dealt(l % 16) + l / 16 of the super tile; turn that into tile l
+    s_turn[wave][4u * dir_dealt(lane & 15) + (lane >> 4)] = mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 x = s_turn[wave][lane];
+    const u32 incl = wave_scan_incl(x, lane);
+    if (lane == 63) s_tot[buf][wave] = incl;
+    lds_barrier();  // not __syncthreads(): the next round's loads stay in flight
+    u32 before = carry, all = 0;
+#pragma unroll
+    for (int w = 0; w < kW; ++w) {
+      const u32 tw = s_tot[buf][w];
+      before += w < wave ? tw : 0u;
+      all += tw;
     }
+    carry += all;
+    const u64 wt = sb * kSuperWt + lane;
+    if (sb < sb1 && wt < n_wt) wt_rel[wt] = before + incl - x;
     buf ^= 1;  // the buffer written two rounds on is free: the next round's barrier lies in between
+  };
+  for (u64 sbb = sb0; sbb < sb1; sbb += kW) {
+    if (sbb + kW < sb1) round(sbb, std::true_type{});
+    else round(sbb, std::false_type{});
   }
-  }
-  if (t == 0) mega_sum[blockIdx.x] = base;
+  if (threadIdx.x == 0) mega_sum[blockIdx.x] = carry;
 }
 
 // ---------------------------------------------------------------------------

@@ -96,6 +96,15 @@ __device__ __forceinline__ u32 row_scan_incl(u32 x) {
   x += dpp_zero<0x118, 0xF>(x);
   return x;
 }
+// Sum over each row of 16 lanes, in every lane of the row (a butterfly: quad_perm, row_half_mirror,
+// row_mirror reach the partner lanes).
+__device__ __forceinline__ u32 row_sum_all(u32 x) {
+  x += (u32)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  x += (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  x += (u32)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, false);  // row_half_mirror: lane i <- 7 - i of its half row
+  x += (u32)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, false);  // row_mirror: lane i <- 15 - i
+  return x;
+}
 // Value of lane 63 (wave-uniform).
 __device__ __forceinline__ u32 wave_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
 // Value of the previous lane; lane 0 receives `first`.
@@ -213,6 +222,25 @@ __device__ __forceinline__ u32 word_len(u32 w_masked, u32 nv) {
   }
   if (V == V1234) return nv + lo + 2u * hi;
   return lo + 2u * hi + __popc(w_masked & (w_masked >> 1) & 0x55555555u);
+}
+
+// Data bytes coded by the 16 keys (64 values, all present) in the four dwords of q.
+// With a = ones among the code bits, b = ones among the high bits of the codes and
+// c = codes with both bits set:  1234: 64 + a + b;  0124: a + b + c;  1248: 64 + a + 2 b + 3 c
+// (the same sums as word_len, regrouped so that v_bcnt's free accumulate does the adding).
+template <int V>
+__device__ __forceinline__ u32 dir_counts(const uint4& q) {
+  const u32 w[4] = {q.x, q.y, q.z, q.w};
+  u32 a = V == V0124 ? 0u : 64u, b = 0, c = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    a += __popc(w[d]);
+    b += __popc(w[d] & 0xAAAAAAAAu);
+    if (V != V1234) c += __popc(w[d] & (w[d] >> 1) & 0x55555555u);
+  }
+  if (V == V1234) return a + b;
+  if (V == V0124) return a + b + c;
+  return a + 2u * b + 3u * c;
 }
 
 __device__ __forceinline__ u32 zz_enc(u32 v) { return (v << 1) ^ (0u - (v >> 31)); }

@@ -116,24 +116,32 @@ __global__ __launch_bounds__(NT) void k_validate_sum(const u8* __restrict__ in, 
   }
   if (whole) {  // workgroup-uniform
     // Unconditional loads at a clamped piece index (a load under a branch makes the compiler wait for
-    // ALL outstanding loads at every use); what lies past the end is loaded from the last whole piece
-    // and never added.
-    auto load = [&](u64 c) -> uint4 { return ld_u128(in + (min(c, whole - 1) << 4)); };
+    // ALL outstanding loads at every use); what lies past the end is never added.
+    // A piece index past the end is replaced by the thread's OWN first piece (a cache hit at an address no
+    // other thread asks for): sending every such load to the last whole piece makes thousands of
+    // wavefronts queue on one cache line, which cost more than reading the whole key block.
     const u64 stride = (u64)gridDim.x * NT;
     const u64 first = (u64)blockIdx.x * NT + threadIdx.x;
+    const u64 own = min(first, whole - 1);
+    auto load = [&](u64 c) -> uint4 { return ld_u128(in + ((c < whole ? c : own) << 4)); };
     uint4 k[kValAhead];
 #pragma unroll
     for (int i = 0; i < kValAhead; ++i) k[i] = load(first + stride * i);
     // unrolled kValAhead times: every load keeps its own register (rotating the registers by moves
     // would wait for the loads being moved)
-    for (u64 cb = first; cb < whole; cb += stride * kValAhead) {
+    u32 quick = 0;  // a thread adds at most 2^26 / 1024 pieces of at most 256 bytes
+    for (u64 wb = (u64)blockIdx.x * NT; wb < whole; wb += stride * kValAhead) {  // the workgroup's first piece: scalar
 #pragma unroll
       for (int r = 0; r < kValAhead; ++r) {
-        const u64 c = cb + stride * r;
-        if (c < whole) add_piece(k[r], c);
+        const u64 c = wb + stride * r + threadIdx.x;
+        // scalar: every piece of the workgroup in this round is a whole piece whose 64 values all exist
+        const u64 wg_end = wb + stride * r + NT;
+        if (wg_end <= whole && (wg_end << 6) <= (u64)count) quick += dir_counts<V>(k[r]);
+        else if (c < whole) add_piece(k[r], c);
         k[r] = load(c + stride * kValAhead);  // behind the last use: the load lands in the register it frees
       }
     }
+    acc += quick;
   }
   const u64 tot = block_sum64(acc, s_tmp);
   if (threadIdx.x == 0) {
