@@ -150,17 +150,54 @@ __attribute__((target("sse4.1"))) uint32_t encode_groups_sse41(const uint32_t* i
   const __m128i gather = _mm_setr_epi8(0, 4, 8, 12, -128, -128, -128, -128, -128, -128, -128, -128, -128, -128, -128, -128);
   __m128i before = _mm_set1_epi32((int)prev);
   uint8_t* d = data;
-  for (uint32_t g = 0; g < groups; ++g) {
+  uint32_t g = 0;
+  // Four groups at a time: their 16 width codes are worked out together and folded into four key
+  // bytes with two multiply-adds, so that the only chain from group to group is the data pointer
+  // (d += len[key]: a table load and an add) and not the whole classification.
+#define SVBCPU_CODES(v) /* 3 - [v <= t1] - [v <= t2] - [v <= t3]  (each compare gives -1 where true) */ \
+  _mm_add_epi32(_mm_add_epi32(_mm_add_epi32(three, _mm_cmpeq_epi32(_mm_min_epu32((v), t1), (v))),      \
+                              _mm_cmpeq_epi32(_mm_min_epu32((v), t2), (v))),                           \
+                _mm_cmpeq_epi32(_mm_min_epu32((v), t3), (v)))
+  const __m128i pair = _mm_set1_epi16(0x0401), quad = _mm_set1_epi32(0x00100001);
+  const __m128i zero = _mm_setzero_si128(), ones8 = _mm_set1_epi8(1), weights = _mm_set1_epi32(0x08040201);
+  // index = set of non-zero bytes; 1234: the highest non-zero byte's number; 0124: that plus one, at most 3
+  const __m128i lut = V == k1234 ? _mm_setr_epi8(0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3)
+                                 : _mm_setr_epi8(0, 1, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3);
+  for (; g + 4 <= groups; g += 4) {
+    __m128i v[4];
+    for (int u = 0; u < 4; ++u) {
+      v[u] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in + 4 * (size_t)(g + u)));
+      if (DELTA) {
+        const __m128i shifted = _mm_alignr_epi8(v[u], before, 12);  // {prev, v0, v1, v2}
+        before = v[u];
+        v[u] = _mm_sub_epi32(v[u], shifted);
+      }
+    }
+    // A value's width code follows from WHICH of its four bytes are non-zero: give byte k the weight 1 << k,
+    // add the weights of the non-zero bytes of every value (0..15) and look the code up, 16 values at a time.
+    const __m128i n0 = _mm_andnot_si128(_mm_cmpeq_epi8(v[0], zero), weights), n1 = _mm_andnot_si128(_mm_cmpeq_epi8(v[1], zero), weights),
+                  n2 = _mm_andnot_si128(_mm_cmpeq_epi8(v[2], zero), weights), n3 = _mm_andnot_si128(_mm_cmpeq_epi8(v[3], zero), weights);
+    const __m128i s01 = _mm_hadd_epi16(_mm_maddubs_epi16(n0, ones8), _mm_maddubs_epi16(n1, ones8)),
+                  s23 = _mm_hadd_epi16(_mm_maddubs_epi16(n2, ones8), _mm_maddubs_epi16(n3, ones8));
+    const __m128i c16 = _mm_shuffle_epi8(lut, _mm_packus_epi16(s01, s23));  // one code per byte, in order
+    const __m128i k32 = _mm_madd_epi16(_mm_maddubs_epi16(c16, pair), quad);  // c0 + 4 c1 + 16 c2 + 64 c3 per group
+    const uint32_t k4 = (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(k32, gather));
+    std::memcpy(keys + g, &k4, 4);
+    for (int u = 0; u < 4; ++u) {
+      const unsigned key = (k4 >> (8 * u)) & 0xFFu;
+      _mm_storeu_si128(reinterpret_cast<__m128i*>(d),
+                       _mm_shuffle_epi8(v[u], _mm_load_si128(reinterpret_cast<const __m128i*>(T.mask[V][key]))));
+      d += T.len[V][key];
+    }
+  }
+  for (; g < groups; ++g) {
     __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in + 4 * (size_t)g));
     if (DELTA) {
       const __m128i shifted = _mm_alignr_epi8(v, before, 12);  // {prev, v0, v1, v2}
       before = v;
       v = _mm_sub_epi32(v, shifted);
     }
-    // code = 3 - [v <= t1] - [v <= t2] - [v <= t3]  (each compare gives -1 where true)
-    __m128i c = _mm_add_epi32(three, _mm_cmpeq_epi32(_mm_min_epu32(v, t1), v));
-    c = _mm_add_epi32(c, _mm_cmpeq_epi32(_mm_min_epu32(v, t2), v));
-    c = _mm_add_epi32(c, _mm_cmpeq_epi32(_mm_min_epu32(v, t3), v));
+    const __m128i c = SVBCPU_CODES(v);
     const uint32_t packed = (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(c, gather));  // one code per byte
     const unsigned key = (packed * 0x01041040u) >> 24;  // c0 | c1 << 2 | c2 << 4 | c3 << 6
     keys[g] = (uint8_t)key;
@@ -168,6 +205,7 @@ __attribute__((target("sse4.1"))) uint32_t encode_groups_sse41(const uint32_t* i
                      _mm_shuffle_epi8(v, _mm_load_si128(reinterpret_cast<const __m128i*>(T.mask[V][key]))));
     d += T.len[V][key];
   }
+#undef SVBCPU_CODES
   if (DELTA && groups) prev = in[4 * (size_t)groups - 1];
   keys += groups;
   data = d;

@@ -11,7 +11,13 @@ tot = 1 << 27
 codec = svb.DeviceCodec(1 << 20, dev)
 g = torch.Generator(device=dev); g.manual_seed(1)
 gaps = torch.randint(0, 1 << 12, (tot,), generator=g, device=dev, dtype=torch.int64)
-for L in (4, 16, 64, 256, 300, 512, 1000, 1024, 1100, 1536, 4096, 16384):
+lengths = (4, 16, 64, 256, 300, 512, 1000, 1024, 1100, 1536, 4096, 16384)
+if len(sys.argv) > 1:  # tools/batch_sweep.py "4,16,64" [batch_chunk]
+    lengths = tuple(int(x) for x in sys.argv[1].split(","))
+if len(sys.argv) > 2:
+    codec.lib.svbgpu_set_option(b"batch_chunk", int(sys.argv[2]))
+    print("batch_chunk", sys.argv[2])
+for L in lengths:
     nl = tot // L
     n = nl * L
     vals = gaps[:n].to(torch.int32).contiguous()
