@@ -12,8 +12,9 @@
  *     SSSE3 code inside the library, same bytes either way) because two PCIe
  *     crossings cost more than the work.  The threshold is the option
  *     "host_cpu_cutoff" of svbgpu_set_option (streamvbyte_gpu.h); 0 sends every
- *     call to the GPU.  Without a usable gfx950 device the larger calls print a
- *     message and abort(): this API has no error channel.
+ *     call to the GPU.  Without a usable gfx950 device every call runs on the
+ *     calling thread.  A HIP failure in the middle of a GPU call prints a message
+ *     and abort()s: this API has no error channel.
  *   - Device pointers are used in place, no copies, always on the GPU.  The
  *     kernels run on a stream of the library's own; before they start the
  *     library waits for everything the caller has queued on the device

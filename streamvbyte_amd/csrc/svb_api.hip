@@ -964,9 +964,10 @@ bool run_on_host(size_t count, std::initializer_list<const void*> ptrs) {
 
 // Host <-> device copies of the host-pointer API.  HIP never sees a pageable
 // caller pointer: such memory moves through the context's own page-locked
-// chunks with plain memcpy on this thread, two chunks in flight.  (Handing
-// pageable pointers of many threads to hipMemcpyAsync at once ended in heap
-// corruption and aborts inside the runtime; callers' buffers share pages.)
+// chunks with plain memcpy on this thread, two chunks in flight (option
+// "host_stage_pageable"; an abort once seen with eight threads handing pageable
+// pointers to hipMemcpyAsync could not be brought back with staging off, so
+// this is a precaution).
 // copy_in returns when the source has been read, copy_out when the destination
 // holds the data; both keep the order of the context's stream.
 bool g_stage_pageable() { return o_host_stage_pageable.load(std::memory_order_relaxed) != 0; }
