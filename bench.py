@@ -116,17 +116,22 @@ def time_steps(torch, fn, steps, warmup, dist=None):
 
 
 def event_ms(torch, fn, iters, warmup=2):
-    """mean milliseconds of fn() measured with HIP events on the current stream"""
+    """mean milliseconds of fn() over `iters` back-to-back calls, one pair of HIP events on the current
+    stream around all of them (an event record between the calls is a queue packet of its own and
+    costs each call about 3 microseconds); three such runs, the middle one is returned too"""
     for _ in range(warmup):
         fn()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in evs:
+    runs = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(iters):
+            fn()
         b.record()
-    torch.cuda.synchronize()
-    ms = sorted(a.elapsed_time(b) for a, b in evs)
-    return float(np.mean(ms)), float(ms[len(ms) // 2])
+        torch.cuda.synchronize()
+        runs.append(a.elapsed_time(b) / iters)
+    runs.sort()
+    return float(np.mean(runs)), float(runs[1])
 
 
 def cpu_share():
