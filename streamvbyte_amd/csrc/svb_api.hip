@@ -82,6 +82,18 @@ inline unsigned stream_grid(unsigned long long work_blocks, int per_cu) {
   return (unsigned)(work_blocks < cap ? (work_blocks ? work_blocks : 1) : cap);
 }
 
+// Runs `stmt` with the constexpr int `NTV` set to `nt` if `nt` is one of the listed values, else to 0:
+// one kernel instantiation per listed policy.
+#define SVB_NT_CASE(v, NTV, ...) case v: { constexpr int NTV = v; __VA_ARGS__; } break;
+#define SVB_NT_SWITCH_023(nt, NTV, ...) \
+  switch (nt) { SVB_NT_CASE(2, NTV, __VA_ARGS__) SVB_NT_CASE(3, NTV, __VA_ARGS__) default: { constexpr int NTV = 0; __VA_ARGS__; } }
+#define SVB_NT_SWITCH_013(nt, NTV, ...) \
+  switch (nt) { SVB_NT_CASE(1, NTV, __VA_ARGS__) SVB_NT_CASE(3, NTV, __VA_ARGS__) default: { constexpr int NTV = 0; __VA_ARGS__; } }
+#define SVB_NT_SWITCH_03(nt, NTV, ...) \
+  switch (nt) { SVB_NT_CASE(3, NTV, __VA_ARGS__) default: { constexpr int NTV = 0; __VA_ARGS__; } }
+#define SVB_NT_SWITCH_01(nt, NTV, ...) \
+  switch (nt) { SVB_NT_CASE(1, NTV, __VA_ARGS__) default: { constexpr int NTV = 0; __VA_ARGS__; } }
+
 // Tuning knobs (svbgpu_set_option): process-wide atomics, read ONCE at the top of
 // an API call into a plain struct that travels down to the launches, so a call
 // never runs on half of a change made by another thread and what a call checks
@@ -99,13 +111,17 @@ struct Options {
   unsigned debug;        // timing-only ablations (wrong results!)
   int zigzag_piece;      // values per device scan of the host-pointer zigzag_delta_decode
   int encode_pipeline;   // 1: k_encode_pipe (two half-size tiles in flight per workgroup), 0: k_encode
+  int encode_ticket_early;  // k_encode_pipe: 1 requests a tile's ticket one store phase before the tile is loaded
   int host_cpu_cutoff;   // host-pointer calls on fewer values than this run on the host codec (svb_cpu.h)
   int host_serialize;    // host-pointer calls: one at a time per device inside the runtime
   int host_stage_pageable;  // host-pointer calls: pageable caller memory moves through page-locked chunks
+  int nt_threshold_mib;  // a call's loads / stores are non-temporal when it reads / writes at least this many MiB
+                         // (-1: never, 0: always)
+  int nt_force;          // -1: by size; 0..3: this policy whatever the size (bit 0 loads, bit 1 stores)
 };
 std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
-    o_encode_qw{4}, o_encode_pipeline{1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
-    o_host_stage_pageable{1};
+    o_encode_qw{4}, o_encode_pipeline{1}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
+    o_host_stage_pageable{1}, o_nt_threshold_mib{128}, o_nt_force{-1};
 inline Options options() {
   Options o;
   const auto rl = std::memory_order_relaxed;
@@ -116,6 +132,7 @@ inline Options options() {
   o.encode_waves = o_encode_waves.load(rl);
   o.encode_qw = o_encode_qw.load(rl);
   o.encode_pipeline = o_encode_pipeline.load(rl);
+  o.encode_ticket_early = o_encode_ticket_early.load(rl);
   o.batch_lists_per_wave = o_batch_lists_per_wave.load(rl);
   o.batch_chunk = o_batch_chunk.load(rl);
   o.debug = (unsigned)o_debug.load(rl);
@@ -123,7 +140,28 @@ inline Options options() {
   o.host_cpu_cutoff = o_host_cpu_cutoff.load(rl);
   o.host_serialize = o_host_serialize.load(rl);
   o.host_stage_pageable = o_host_stage_pageable.load(rl);
+  o.nt_threshold_mib = o_nt_threshold_mib.load(rl);
+  o.nt_force = o_nt_force.load(rl);
   return o;
+}
+
+// Non-temporal policy of a call that reads `load_bytes` and writes `store_bytes` once each (lower bounds
+// where the exact size is not known before the call): see ld_stream16 / st_stream16.
+inline int nt_policy(const Options& o, unsigned long long load_bytes, unsigned long long store_bytes) {
+  if (o.nt_force >= 0) return o.nt_force;
+  if (o.nt_threshold_mib < 0) return 0;
+  // Stores: an output of half the Infinity Cache (256 MiB) or more cannot wait there for its consumer.
+  // Loads: an input that size is still served from the cache when a call repeats on it and little else
+  // is written (exact size at 2^26 values: 0.70 against 0.57 of peak), so they also ask for a footprint
+  // beyond the cache.  Measured with tools/nt_sweep.py at 2^24 ... 2^28 values.
+  const unsigned long long t = (unsigned long long)o.nt_threshold_mib << 20;
+  const bool stores = store_bytes >= t;
+  const bool loads = load_bytes >= t && 2 * (load_bytes + store_bytes) >= 5 * t;
+  return (loads ? kNtLoads : 0) | (stores ? kNtStores : 0);
+}
+// Least size of a stream of `count` values: the keys plus one byte per value (1234) or nothing (0124).
+inline unsigned long long min_stream_bytes(int v, unsigned long long count) {
+  return (count + 3) / 4 + (v == V1234 ? count : 0);
 }
 
 inline WsHeader* ws_hdr(void* ws) { return reinterpret_cast<WsHeader*>(ws); }
@@ -178,8 +216,9 @@ void launch_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint3
   const WsLayout L = ws_layout(count);
   const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, o.decode_per_cu);
   if (o.decode_shortcut)
-    hipLaunchKernelGGL((k_decode<V, ZZ, true>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
-                       ws_dir(ws, L), d_consumed, 0u);
+    SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
+                      hipLaunchKernelGGL((k_decode<V, ZZ, true, 0, NTV>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out,
+                                         count, ws_dir(ws, L), d_consumed, 0u))
   else
     hipLaunchKernelGGL((k_decode<V, ZZ, false>), dim3(grid), dim3(kBlock), 0, st, d_in, d_out, count,
                        ws_dir(ws, L), d_consumed, 0u);
@@ -189,9 +228,11 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
                          void* ws, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
   if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
-    hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024), 0, st, d_in,
-                       d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
-                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+    SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
+                      hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16, NTV>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024),
+                                         0, st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
+                                         LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
+                                         d_consumed))
   else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st, d_in,
                        d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
@@ -278,8 +319,13 @@ void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, ui
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
-  if (full_tiles)
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW>), dim3(stream_grid(full_tiles, NW == 8 ? 2 : (QW > 2 || V != V1234 ? 4 : 5))), dim3(NW * 64),
+  const unsigned grid = stream_grid(full_tiles, NW == 8 ? (QW <= 2 ? 3 : 2) : (QW > 2 || V != V1234 ? 4 : 5));
+  if (full_tiles && QW == 4)  // the shapes in regular use take the non-temporal policy of the call
+    SVB_NT_SWITCH_013(nt_policy(o, 4ull * count, min_stream_bytes(V, count)), NTV,
+                      hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW, (QW == 4 ? NTV : 0)>), dim3(grid), dim3(NW * 64), 0,
+                                         st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps))
+  else if (full_tiles)
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW>), dim3(grid), dim3(NW * 64),
                        0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps);
   if (ragged)  // the one tile that runs past the end of the stream: same look-back words
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
@@ -298,9 +344,13 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
   const LbWords status{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2) ? ws_at<u64>(ws, L.total) : nullptr;
+  // the ticket a phase early pays for 0124 (short store phases), not for 1234
+  const u32 early = o.encode_ticket_early < 0 ? (V == V0124 ? 1u : 0u) : (u32)o.encode_ticket_early;
   if (full_tiles)
-    hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, QUANT, NW>), dim3(stream_grid(full_tiles, 2)), dim3(NW * 64), 0, st,
-                       d_in, count, full_tiles, d_out, prev, h, status, d_written, stamps);
+    SVB_NT_SWITCH_013(nt_policy(o, 4ull * count, min_stream_bytes(V, count)), NTV,
+                      hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, QUANT, NW, NTV>), dim3(stream_grid(full_tiles, 2)),
+                                         dim3(NW * 64), 0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written,
+                                         stamps, early))
   if (ragged)
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, 0u, (u64*)nullptr);
@@ -313,6 +363,7 @@ void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8
   // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
   if (o.encode_pipeline && !D && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (o.encode_qw == 2 && o.encode_waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_waves == 8 && V == V1234)  // 0124 on small-valued input is faster with the smaller tile
     launch_encode_qw<V, D, Z, 4, false, V == V1234 ? 8 : kWaves>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
@@ -322,7 +373,8 @@ template <int V, bool D, bool Z>
 void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* d_bytes,
                  hipStream_t st) {
   const unsigned grid = stream_grid(((unsigned long long)count / 4 + kSizeChunk - 1) / kSizeChunk, 8);
-  hipLaunchKernelGGL((k_size<V, D, Z>), dim3(grid), dim3(kBlock), 0, st, d_in, count, prev, d_bytes);
+  SVB_NT_SWITCH_01(nt_policy(options(), 4ull * count, 0), NTV,
+                   hipLaunchKernelGGL((k_size<V, D, Z, NTV>), dim3(grid), dim3(kBlock), 0, st, d_in, count, prev, d_bytes))
 }
 
 #define DISPATCH_VDZ(fn, variant, flags, ...)                                              \
@@ -377,6 +429,9 @@ int svbgpu_set_option(const char* name, int value) {
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
       {"encode_pipeline", &o_encode_pipeline, [](int v) { return v == 0 || v == 1; }},
+      {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
+      {"nt_threshold_mib", &o_nt_threshold_mib, [](int v) { return v >= -1; }},
+      {"nt_force", &o_nt_force, [](int v) { return v >= -1 && v <= 3; }},
       {"host_cpu_cutoff", &o_host_cpu_cutoff, [](int v) { return v >= 0; }},
       {"host_serialize", &o_host_serialize, [](int v) { return v == 0 || v == 1; }},
       {"host_stage_pageable", &o_host_stage_pageable, [](int v) { return v == 0 || v == 1; }},
@@ -625,9 +680,11 @@ static int zigzag_launch(int mode, const uint32_t* in, uint32_t* out, size_t n, 
   if (!in || !out) return SVBGPU_EINVAL;
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   const unsigned grid = stream_grid(((unsigned long long)n / 4 + kBlock - 1) / kBlock + 1, 0);
-  if (mode == 0) hipLaunchKernelGGL(k_zigzag<0>, dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
-  else if (mode == 1) hipLaunchKernelGGL(k_zigzag<1>, dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
-  else hipLaunchKernelGGL(k_zigzag<2>, dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+  SVB_NT_SWITCH_03(nt_policy(options(), 4ull * n, 4ull * n), NTV, {
+    if (mode == 0) hipLaunchKernelGGL((k_zigzag<0, NTV>), dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+    else if (mode == 1) hipLaunchKernelGGL((k_zigzag<1, NTV>), dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+    else hipLaunchKernelGGL((k_zigzag<2, NTV>), dim3(grid), dim3(kBlock), 0, S(stream), in, out, (u64)n, prev);
+  })
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
@@ -657,9 +714,11 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   const u32 n_tiles16 = (u32)((L.n_wt + 63) / 64);
   const int scan_waves = options().scan_waves;
   if (scan_waves == 16)
-    hipLaunchKernelGGL((k_running_sum<true, 16>), dim3(stream_grid(n_tiles16, 1)), dim3(1024), 0, S(stream), d_in,
-                       reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles16, ws_hdr(ws),
-                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
+    SVB_NT_SWITCH_03(nt_policy(options(), 4ull * count, 4ull * count), NTV,
+                     hipLaunchKernelGGL((k_running_sum<true, 16, NTV>), dim3(stream_grid(n_tiles16, 1)), dim3(1024), 0,
+                                        S(stream), d_in, reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev,
+                                        n_tiles16, ws_hdr(ws),
+                                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}))
   else if (scan_waves == 8)
     hipLaunchKernelGGL((k_running_sum<true, 8>), dim3(stream_grid(n_tiles8, 2)), dim3(512), 0, S(stream), d_in,
                        reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles8, ws_hdr(ws),

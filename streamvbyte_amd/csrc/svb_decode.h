@@ -191,6 +191,7 @@ __device__ __forceinline__ u32 scan_keys_to_entries(u32 w, u32 nv, int lane, u32
 
 // Stage the contiguous data span [dp, dp+total) into LDS with aligned 16-byte
 // loads.  Returns the offset of dp's first byte inside the LDS image.
+template <bool NTL = false>
 __device__ __forceinline__ u32 stage_span(const u8* dp, u32 total, int lane, u8* sdata) {
   const u32 shift = (u32)((uintptr_t)dp & 15u);
   const uint4* src = reinterpret_cast<const uint4*>(dp - shift);
@@ -203,7 +204,7 @@ __device__ __forceinline__ u32 stage_span(const u8* dp, u32 total, int lane, u8*
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     r[i] = make_uint4(0, 0, 0, 0);
-    if (64u * i < nch) r[i] = src[min((u32)lane + 64u * i, last)];
+    if (64u * i < nch) r[i] = ld_stream16<NTL>(src + min((u32)lane + 64u * i, last));
   }
   uint4* d = reinterpret_cast<uint4*>(sdata);
 #pragma unroll
@@ -236,7 +237,7 @@ __device__ __forceinline__ uint4 extract_group(u32 entry, u32 shift, const u8* s
 // One wave tile, keys -> values: lane ends up with the (up to) 4 groups
 // j*64+lane, j = 0..3, of the wave tile whose keys it holds blocked in `w`.
 // Values past `nints` are returned as zero.  Returns the tile's data bytes.
-template <int V, bool ZZ, bool SHORTCUT = true, bool TABLE = false>
+template <int V, bool ZZ, bool SHORTCUT = true, bool TABLE = false, bool NTL = false>
 __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, int lane, WaveLds& S,
                                                uint4 (&v)[4]) {
   // A full wave tile whose 256 keys are all zero (every value below 256; dense
@@ -259,7 +260,7 @@ __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, i
   }
   const u32 nv = nints > 16u * lane ? min(nints - 16u * lane, 16u) : 0u;
   const u32 total = scan_keys_to_entries<V, TABLE>(w, nv, lane, S.ent);
-  const u32 shift = stage_span(dp, total, lane, S.data);
+  const u32 shift = stage_span<NTL>(dp, total, lane, S.data);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -314,9 +315,10 @@ __device__ __forceinline__ uint4 values_of_group(const uint4& d, u32 key, u32 nv
 }
 
 // Store group `first..first+3` of a stream of `count` values.
+template <bool NTS = false>
 __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, const uint4& v) {
   if (first + 4 <= count) {
-    __builtin_memcpy(out + first, &v, 16);
+    st_stream16<NTS>(out + first, v);
   } else if (first < count) {
     out[first] = v.x;
     if (first + 1 < count) out[first + 1] = v.y;
@@ -334,8 +336,8 @@ __device__ __forceinline__ void store_group(u32* out, u64 first, u64 count, cons
 // + 4 (out).
 // OUT: 0 = the integers; 1 = float32 (int32)value * scale (dequantise fused into the
 // store); 2 = the same added to what out already holds (dequantise-accumulate).
-// scale travels as the bits of `aux`.
-template <int V, bool ZZ, bool SHORTCUT, int OUT = 0>
+// scale travels as the bits of `aux`.  NT: non-temporal stream loads (bit 0) / value stores (bit 1).
+template <int V, bool ZZ, bool SHORTCUT, int OUT = 0, int NT = 0>
 __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
                                                    u32* __restrict__ out, u32 count,
                                                    Dir dir, u64* __restrict__ consumed, u32 aux) {
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
     const u64 int0 = (u64)wt * kWtInts;
     const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
     uint4 v[4];
-    const u32 total = decode_wavetile<V, ZZ, SHORTCUT, kTable>(w, nints, data_base + doff, lane, S, v);
+    const u32 total = decode_wavetile<V, ZZ, SHORTCUT, kTable, (NT & kNtLoads) != 0>(w, nints, data_base + doff, lane, S, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u64 first = int0 + 4u * (j * 64 + lane);
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_decode(const u8* __restrict__ in,
         }
         r = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
       }
-      store_group(out, first, count, r);
+      store_group<(NT & kNtStores) != 0>(out, first, count, r);
     }
     if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff + total;
     if (wt_n >= n_wt) break;

@@ -59,7 +59,7 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
   return add;
 }
 
-template <int V, bool ZZ, int NW = kWaves>
+template <int V, bool ZZ, int NW = kWaves, int NT = 0>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
     Dir dir, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     if (wt < n_wt) {
       const u64 int0 = (u64)wt * kWtInts;
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
-      const u32 total = decode_wavetile<V, ZZ>(w[q], nints, data_base + doff[q], lane, S, v[q]);
+      const u32 total = decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w[q], nints, data_base + doff[q], lane, S, v[q]);
       if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + total;
     }
   }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     for (int j = 0; j < 4; ++j) {
       uint4 r = v[q][j];
       r.x += add; r.y += add; r.z += add; r.w += add;
-      store_group(out, ((u64)(wt0 + q)) * kWtInts + 4u * (j * 64 + lane), count, r);
+      store_group<(NT & kNtStores) != 0>(out, ((u64)(wt0 + q)) * kWtInts + 4u * (j * 64 + lane), count, r);
     }
 }
 
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_delta_decode2(const u8* __restrict__
 // Plain inclusive running sum out[i] = seed + sum_{j<=i} f(in[j]), f = identity
 // or un-zigzag (zigzag_delta_decode).  8 B per value.
 // NW waves per workgroup, each with 4 wave tiles: a tile of the look-back holds NW * 4096 values.
-template <bool ZZ, int NW = kWaves>
+template <bool ZZ, int NW = kWaves, int NT = 0>
 __global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restrict__ in,
                                                            u32* __restrict__ out, u32 count,
                                                            u32 seed, u32 n_tiles,
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restric
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        uint4 r = src[(u32)lane + (u32)(q * 256 + j * 64)];
+        uint4 r = ld_stream16<(NT & kNtLoads) != 0>(src + ((u32)lane + (u32)(q * 256 + j * 64)));
         if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
         v[q][j] = r;
       }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restric
       for (int j = 0; j < 4; ++j) {
         uint4 r = v[q][j];
         r.x += add; r.y += add; r.z += add; r.w += add;
-        dst[(u32)lane + (u32)(q * 256 + j * 64)] = r;
+        st_stream16<(NT & kNtStores) != 0>(dst + ((u32)lane + (u32)(q * 256 + j * 64)), r);
       }
   } else {
 #pragma unroll

@@ -47,6 +47,27 @@ __device__ __forceinline__ uint4 ld_u128(const u8* p) {
   __builtin_memcpy(&v, p, 16);
   return v;
 }
+// 16-byte global accesses of data that a call reads or writes exactly once (the values and the
+// streams).  NT marks them non-temporal: the line is not kept in L2 / the Infinity Cache, which a long
+// stream would only sweep through, evicting (and writing back) what it displaces.  Kernels take the
+// choice as a template argument (bit 0: loads, bit 1: stores); the launch code picks it from the size
+// of the call -- short streams keep the default policy, their bytes are likely to be used again from
+// the cache by whatever runs next.
+constexpr int kNtLoads = 1, kNtStores = 2;
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+  if (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream16(void* p, const uint4& v) {
+  if (NT) __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+  else *reinterpret_cast<uint4*>(p) = v;
+}
 __device__ __forceinline__ u32 lds_u32(const u8* p) {
   u32 v;
   __builtin_memcpy(&v, p, 4);

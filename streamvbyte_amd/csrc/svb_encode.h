@@ -195,7 +195,7 @@ __device__ __forceinline__ void store_head(u8* image, u32 first_dword, u32 p, u3
 // the tile's 1024 values exist (FULL: all of them).  Assembles the data bytes
 // in the wave's LDS image, copies them to dst[0..total) and the keys to kdst.
 // Returns total.
-template <int V, bool FULL>
+template <int V, bool FULL, bool NTS = false>
 __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&g)[4], u32 nints,
                                                int lane, EncWaveLds& S, u8* dst, u8* kdst) {
   // A full wave tile whose 256 keys are all zero (every value below 256 for
@@ -282,7 +282,7 @@ __device__ __forceinline__ u32 encode_wavetile(const uint4 (&x)[4], const u32 (&
     u8* g0 = dst - a;                          // 16-byte aligned
     uint4* g16 = reinterpret_cast<uint4*>(g0);
     const uint4* l16 = reinterpret_cast<const uint4*>(S.data);
-    for (u32 c = c_lo + lane; c < c_hi; c += 64) g16[c] = l16[c];
+    for (u32 c = c_lo + lane; c < c_hi; c += 64) st_stream16<NTS>(g16 + c, l16[c]);
     const u32 hend = min(16u * c_lo, end);     // head bytes [a, hend)
     const u32 tstart = max(16u * c_hi, hend);  // tail bytes [tstart, end)
     if (lane < 16) {
@@ -326,7 +326,7 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // QUANT: the input holds float32; every value becomes (int32)rintf(x * scale) first
 // (scale travels as the bits of `prev`, which only DELTA uses otherwise) -- the
 // quantise step of gradient compression fused into the encoder's load.
-template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves>
+template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves, int NT = 0>
 __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
 #pragma unroll
     for (int q = 0; q < QW; ++q) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[q][j] = src[(u32)lane + (u32)(q * 256 + j * 64)];
+      for (int j = 0; j < 4; ++j) x[q][j] = ld_stream16<(NT & kNtLoads) != 0>(src + ((u32)lane + (u32)(q * 256 + j * 64)));
     }
   } else {
 #pragma unroll
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
       u32 gq[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) gq[j] = ((kq[0] >> (8 * j)) & 0xFFu) | (((lens4 >> (8 * j)) & 0xFFu) << 24);
-      doff += encode_wavetile<V, true>(x[0], gq, kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
+      doff += encode_wavetile<V, true, (NT & kNtStores) != 0>(x[0], gq, kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
     } else if (wt_first < count) {
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - wt_first);
       doff += encode_wavetile<V, false>(x[0], g[0], nints, lane, S, data_out + doff, out + (wt_first >> 2));
@@ -519,10 +519,10 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
 // tiles per wave).  Handles only tiles that lie wholly inside the stream; the
 // ragged last tile is a launch of k_encode<.., QW, false, .., NW> on the same
 // look-back words.
-template <int V, bool DELTA, bool ZZ, int QW, bool QUANT = false, int NW = 8>
+template <int V, bool DELTA, bool ZZ, int QW, bool QUANT = false, int NW = 8, int NT = 0>
 __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
-    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u64* __restrict__ stamps) {
+    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u64* __restrict__ stamps, u32 early) {
   __shared__ EncWaveLds s_lds[NW];
   __shared__ u32 s_wave_tot[2][NW];
   __shared__ u64 s_prefix;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
       if (tile == last_tile && written) *written = keylen + excl + tile_tot;
       if (stamps) {  // diagnostic build only: wall-clock stamps per tile, 100 MHz
         stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();
-        stamps[5 * (u64)tile + 4] = rounds;
+        stamps[5 * (u64)tile + 4] = rounds | ((u64)blockIdx.x << 32);
       }
     }
   };
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
 #pragma unroll
     for (int q = 0; q < QW; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[q][j] = src[(u32)lane + (u32)(q * 256 + j * 64)];
+      for (int j = 0; j < 4; ++j) x[q][j] = ld_stream16<(NT & kNtLoads) != 0>(src + ((u32)lane + (u32)(q * 256 + j * 64)));
     LbState<kT> polls;
     const bool resolving = wave == 0 && tile_res != 0xFFFFFFFFu;
     if (resolving) polls = lb2_begin<kT>(lb, tile_res, lane);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
       u32 gq[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) gq[j] = ((kq[0] >> (8 * j)) & 0xFFu) | (((lens4 >> (8 * j)) & 0xFFu) << 24);
-      doff += encode_wavetile<V, true>(x[0], gq, kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
+      doff += encode_wavetile<V, true, (NT & kNtStores) != 0>(x[0], gq, kWtInts, lane, S, data_out + doff, out + (wt_first >> 2));
 #pragma unroll
       for (int r = 0; r + 1 < QW; ++r) {
         kq[r] = kq[r + 1];
@@ -646,6 +646,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
     if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 3] = __builtin_amdgcn_s_memrealtime();
   };
 
+  // early: the ticket of the tile after next is requested right after a publish and collected after the
+  // store phase that follows, so its round trip (about a microsecond under load) is off the tile loop.
+  // The workgroup then holds a ticket through one store phase before it loads that tile; between the
+  // draw and the tile's publish it still waits only for smaller tickets.
+  auto request = [&]() -> u32 { return threadIdx.x == 0 ? atomicAdd(&hdr->ticket, 1u) : 0u; };
+  auto collect = [&](u32 requested) -> u32 {
+    if (threadIdx.x == 0) s_tile = requested;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(s_tile);
+  };
+
   uint4 xa[QW][4], xb[QW][4];
   u32 kqa[QW], kqb[QW];
   u32 tile_a = draw();
@@ -653,15 +664,17 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
   load(tile_a, 0, xa, kqa, 0xFFFFFFFFu, 0u);
   __syncthreads();
   u32 tot_a = publish(tile_a, 0);
+  u32 requested = early ? request() : 0u;
   int buf = 0;
   for (;;) {
-    const u32 tile_b = draw();
+    const u32 tile_b = early ? collect(requested) : draw();
     const bool more = tile_b < n_tiles;  // workgroup-uniform
     if (more) load(tile_b, buf ^ 1, xb, kqb, tile_a, tot_a);
     else if (wave == 0) resolve(tile_a, tot_a, nullptr);
     __syncthreads();
     u32 tot_b = 0;
     if (more) tot_b = publish(tile_b, buf ^ 1);
+    if (more && early) requested = request();
     store(tile_a, buf, xa, kqa);
     if (!more) break;
 #pragma unroll

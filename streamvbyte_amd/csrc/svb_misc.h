@@ -36,7 +36,7 @@ __device__ __forceinline__ u64 block_sum64(u64 x, u64* s_tmp) {
 // (or the difference) first.
 // *result must be zero before the launch.  Reads 4 B per value.
 constexpr u64 kSizeChunk = 64 * kBlock;  // quads (of 4 values) per workgroup: 256 KiB of input per atomic
-template <int V, bool DELTA, bool ZZ>
+template <int V, bool DELTA, bool ZZ, int NT = 0>
 __global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32 count, u32 prev,
                                                  u64* __restrict__ result) {
   __shared__ u64 s_tmp[kWaves];
@@ -45,8 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32
   // workgroup b takes the contiguous quads [b * kSizeChunk, (b + 1) * kSizeChunk) (grid-stride beyond that)
   for (u64 c0 = (u64)blockIdx.x * kSizeChunk; c0 < nquads; c0 += (u64)gridDim.x * kSizeChunk)
   for (u64 q = c0 + threadIdx.x; q < min(nquads, c0 + kSizeChunk); q += kBlock) {
-    uint4 x;
-    __builtin_memcpy(&x, in + 4 * q, 16);
+    const uint4 x = ld_stream16<(NT & kNtLoads) != 0>(in + 4 * q);
     u32 v[4] = {x.x, x.y, x.z, x.w};
     if (DELTA) {
       const u32 p = q ? in[4 * q - 1] : prev;
@@ -156,13 +155,12 @@ __global__ __launch_bounds__(NT) void k_validate_sum(const u8* __restrict__ in, 
 // ---------------------------------------------------------------------------
 // Zigzag maps (reference src/streamvbyte_zigzag.c:3-29).  8 B per value.
 // MODE 0: encode, 1: decode, 2: delta encode (out[i] = zz(in[i]-in[i-1])).
-template <int MODE>
+template <int MODE, int NT = 0>
 __global__ __launch_bounds__(kBlock) void k_zigzag(const u32* __restrict__ in,
                                                    u32* __restrict__ out, u64 n, u32 prev) {
   const u64 nquads = n >> 2;
   for (u64 q = (u64)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (u64)gridDim.x * kBlock) {
-    uint4 x;
-    __builtin_memcpy(&x, in + 4 * q, 16);
+    const uint4 x = ld_stream16<(NT & kNtLoads) != 0>(in + 4 * q);
     uint4 y;
     if (MODE == 0) {
       y = make_uint4(zz_enc(x.x), zz_enc(x.y), zz_enc(x.z), zz_enc(x.w));
@@ -172,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_zigzag(const u32* __restrict__ in,
       const u32 p = q ? in[4 * q - 1] : prev;
       y = make_uint4(zz_enc(x.x - p), zz_enc(x.y - x.x), zz_enc(x.z - x.y), zz_enc(x.w - x.z));
     }
-    __builtin_memcpy(out + 4 * q, &y, 16);
+    st_stream16<(NT & kNtStores) != 0>(out + 4 * q, y);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const u64 i = (nquads << 2) + threadIdx.x;

@@ -28,6 +28,8 @@ elif mode == "dense":  # dense postings, delta coded
 else:
     values = gen_width_mix(torch, n, 1, "cuda:0")
 out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device="cuda:0")
+if len(sys.argv) > 4:   # encode_pipeline value (2: loads issued a store phase ahead)
+    codec.lib.svbgpu_set_option(b"encode_pipeline", int(sys.argv[4]))
 for _ in range(3):
     codec.encode(values, out=out, **kw)
 codec.lib.svbgpu_set_option(b"debug_ablate", 16)
@@ -37,7 +39,8 @@ codec.lib.svbgpu_set_option(b"debug_ablate", 0)
 tiles = n // 1024 // tile_wt
 st = codec.ws[need: need + 40 * tiles].cpu().numpy().view(np.uint64).reshape(tiles, 5)
 rounds = (st[:, 4] & np.uint64(0xFF)).astype(np.int64)
-res_us = (st[:, 4] >> np.uint64(32)).astype(np.float64) / 100.0
+wg_id = (st[:, 4] >> np.uint64(32)).astype(np.int64)
+res_us = np.zeros(len(wg_id))
 st = st.astype(np.float64)
 t0 = st[:, 0].min()
 start, published, resolved, done = [(st[:, i] - t0) / 100.0 for i in range(4)]
@@ -45,6 +48,17 @@ print(f"tiles {tiles}  kernel span {done.max():.1f} us")
 for name, v in (("load+publish", published - start), ("publish->resolved", resolved - published), ("resolve itself", res_us),
                 ("store", done - resolved), ("total", done - start)):
     print(f"{name:18s} mean {v.mean():7.2f}  p10 {np.percentile(v,10):7.2f}  p50 {np.percentile(v,50):7.2f}  p90 {np.percentile(v,90):7.2f}  max {v.max():7.2f} us")
+# the ticket phase: per workgroup, from the end of a tile's store to the start of the load of the tile after next
+wg = wg_id
+gaps, cycles = [], []
+for w in np.unique(wg)[:64]:
+    idx = np.where(wg == w)[0]
+    idx = idx[np.argsort(start[idx])]
+    for a, c in zip(idx[:-2], idx[2:]):
+        gaps.append(start[c] - done[a])
+    cycles.extend(np.diff(start[idx]))
+gaps, cycles = np.array(gaps), np.array(cycles)
+print(f"ticket phase (store end -> next load start): mean {gaps.mean():.2f} p50 {np.percentile(gaps,50):.2f} p90 {np.percentile(gaps,90):.2f} us;  tile cycle per workgroup: mean {cycles.mean():.2f} us")
 print("poll rounds: mean %.2f p50 %.0f p90 %.0f max %.0f" % (rounds.mean(), np.percentile(rounds, 50), np.percentile(rounds, 90), rounds.max()))
 print("tiles started per us (steady state): %.1f" % ((tiles // 2) / (start[3 * tiles // 4] - start[tiles // 4])))
 for lo in (0, tiles // 2, tiles - 6):
