@@ -402,8 +402,10 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
             kernels = json.load(open(path))["kernels"]
             # the plain 1234 decoder the timed region launches (template arguments: variant 0, no zigzag,
-            # all-zero-key shortcut on, integer output)
-            k = kernels.get("k_decode<0, false, true, 0>") or kernels.get("k_decode<0, false>")
+            # all-zero-key shortcut on, integer output, non-temporal loads and stores as a 2^28-value
+            # stream gets them)
+            k = (kernels.get("k_decode<0, false, true, 0, 3>") or kernels.get("k_decode<0, false, true, 0>")
+                 or kernels.get("k_decode<0, false>"))
             if k:
                 traffic, traffic_src = k["hbm_bytes"], os.path.relpath(path, ROOT)
 

@@ -234,9 +234,11 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
                                          LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
                                          d_consumed))
   else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
-    hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st, d_in,
-                       d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
-                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+    SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
+                      hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8, NTV>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0,
+                                         st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
+                                         LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
+                                         d_consumed))
   else
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
                      d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
@@ -622,12 +624,15 @@ int svbgpu_decode_dequantize(int variant, const uint8_t* d_in, float* d_out, uin
   u32* out = reinterpret_cast<u32*>(d_out);
   const Dir dir = ws_dir(ws, L);
   hipStream_t st = S(stream);
+  // accumulate reads what it then overwrites: those lines are worth keeping until the store, so only
+  // the plain dequantising store follows the call's non-temporal policy
+  const int nt = accumulate ? 0 : nt_policy(options(), min_stream_bytes(variant == SVBGPU_1234 ? V1234 : V0124, count), 4ull * count);
   if (variant == SVBGPU_1234) {
     if (accumulate) hipLaunchKernelGGL((k_decode<V1234, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
-    else            hipLaunchKernelGGL((k_decode<V1234, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
+    else SVB_NT_SWITCH_023(nt, NTV, hipLaunchKernelGGL((k_decode<V1234, true, true, 1, NTV>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits))
   } else {
     if (accumulate) hipLaunchKernelGGL((k_decode<V0124, true, true, 2>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
-    else            hipLaunchKernelGGL((k_decode<V0124, true, true, 1>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits);
+    else SVB_NT_SWITCH_023(nt, NTV, hipLaunchKernelGGL((k_decode<V0124, true, true, 1, NTV>), dim3(grid), dim3(kBlock), 0, st, d_in, out, count, dir, d_consumed, bits))
   }
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;

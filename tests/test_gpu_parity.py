@@ -137,6 +137,41 @@ def test_encoder_tile_sizes(torch_mod, codec, oracle):
                 assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags, qw, waves)
 
 
+def test_cache_policies_and_early_ticket(torch_mod, codec, oracle):
+    """Non-temporal loads / stores (forced on and off, whatever the size) and the encoder's early ticket
+    change no byte and no integer."""
+    from streamvbyte_amd import DELTA, ZIGZAG
+    lib = codec.lib
+    try:
+        for i, n in enumerate([1, 16385, 262144 + 7, (1 << 21) + 3]):
+            v = gen("width_mix", n, 6500 + i)
+            d_v = to_dev(torch_mod, v)
+            for nt in (0, 1, 2, 3):
+                assert lib.svbgpu_set_option(b"nt_force", nt) == 0
+                for early in (0, 1):
+                    assert lib.svbgpu_set_option(b"encode_ticket_early", early) == 0
+                    for variant, flags, prev in ((V1234, 0, 0), (V0124, ZIGZAG, 0), (V1234, DELTA, 99), (V0124, 0, 0)):
+                        src = oracle.zigzag_encode(v.view(np.int32)) if flags & ZIGZAG else v
+                        expect = oracle.encode(variant, src, bool(flags & DELTA), prev)
+                        out, size = codec.encode(d_v, variant=variant, flags=flags, prev=prev)
+                        codec.check()
+                        assert int(size.item()) == expect.size, (n, nt, early, variant, flags)
+                        assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, nt, early, variant, flags)
+                        if early == 0:
+                            dec, used = codec.decode(out, n, variant=variant, flags=flags, prev=prev)
+                            codec.check()
+                            assert int(used.item()) == expect.size
+                            assert np.array_equal(to_np(dec, np.uint32), v), (n, nt, variant, flags)
+                assert int(codec.compressedbytes(d_v).item()) == oracle.encode(V1234, v).size
+                zz = codec.zigzag(d_v, "encode")
+                assert np.array_equal(to_np(zz, np.uint32), oracle.zigzag_encode(v.view(np.int32)))
+                back = codec.zigzag(zz, "delta_decode", 5)
+                assert np.array_equal(to_np(back, np.int32), oracle.zigzag_delta_decode(to_np(zz, np.uint32), 5))
+    finally:
+        lib.svbgpu_set_option(b"nt_force", -1)
+        lib.svbgpu_set_option(b"encode_ticket_early", -1)
+
+
 def test_size_and_validate(torch_mod, codec, oracle):
     for i, n in enumerate(SIZES):
         v = gen("perf_c", n, 5000 + i)

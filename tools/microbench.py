@@ -98,6 +98,8 @@ if want("delta"):
     ops["delta_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
     ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
 
+    ops["delta_decode_w8"] = (opt_with(b"scan_waves", 8, 16, lambda: codec.decode(s3, n, out=out, flags=svb.DELTA)), (4.25 + d3) * n)
+
     def dd_twopass():
         codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)
         codec.decode(s3, n, out=out, flags=svb.DELTA)
