@@ -225,24 +225,27 @@ void launch_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint3
 }
 template <int V, bool ZZ>
 void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out, uint32_t count, uint32_t prev,
-                         void* ws, uint64_t* d_consumed, hipStream_t st) {
+                         void* ws, size_t ws_bytes, uint64_t* d_consumed, hipStream_t st) {
   const WsLayout L = ws_layout(count);
+  // diagnostic stamps (8 words per tile) live behind the regular workspace when the caller
+  // over-allocated it and asked for them
+  u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 64ull * (L.n_wt / 16 + 2) ? ws_at<u64>(ws, L.total) : nullptr;
   if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16, NTV>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024),
                                          0, st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                                          LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
-                                         d_consumed))
+                                         d_consumed, stamps))
   else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8, NTV>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0,
                                          st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                                          LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
-                                         d_consumed))
+                                         d_consumed, stamps))
   else
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
                      d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
-                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed, (u64*)nullptr);
 }
 
 template <int V, bool ZZ>
@@ -263,7 +266,7 @@ void launch_delta_decode2(const Options& o, const uint8_t* d_in, uint32_t* d_out
 
 // decode with the directory already in the workspace
 int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
-               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st) {
+               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st, size_t ws_bytes = 0) {
   const bool zz = flags & SVBGPU_ZIGZAG, delta = flags & SVBGPU_DELTA;
   const bool v0 = variant == SVBGPU_1234;
   if (!delta) {
@@ -274,10 +277,10 @@ int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_i
   } else if (o.delta_lookback) {
     int rc = clear_lookback(count, ws, st);
     if (rc) return rc;
-    if (v0) { if (zz) launch_delta_decode<V1234, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
-              else    launch_delta_decode<V1234, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
-    else    { if (zz) launch_delta_decode<V0124, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
-              else    launch_delta_decode<V0124, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
+    if (v0) { if (zz) launch_delta_decode<V1234, true>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st);
+              else    launch_delta_decode<V1234, false>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st); }
+    else    { if (zz) launch_delta_decode<V0124, true>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st);
+              else    launch_delta_decode<V0124, false>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st); }
   } else {
     if (v0) { if (zz) launch_delta_decode2<V1234, true>(o, d_in, d_out, count, prev, ws, d_consumed, st);
               else    launch_delta_decode2<V1234, false>(o, d_in, d_out, count, prev, ws, d_consumed, st); }
@@ -470,7 +473,7 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
   if (rc) return rc;
   rc = build_directory(variant, d_in, count, ws, S(stream));
   if (rc) return rc;
-  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), ws_bytes);
 }
 
 int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* ws, size_t ws_bytes,

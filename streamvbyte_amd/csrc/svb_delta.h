@@ -16,12 +16,13 @@
 
 namespace svb {
 
-// Turn the 16 uint4 of a wave (4 wave tiles x 4 striped groups) into running
+// Turn the 4 Q uint4 of a wave (Q wave tiles x 4 striped groups) into running
 // sums relative to the wave's first value.  Returns the wave's total.
-__device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[4][4], int lane) {
+template <int Q = 4>
+__device__ __forceinline__ u32 wave_running_sums(uint4 (&v)[Q][4], int lane) {
   u32 run = 0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < Q; ++q)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint4& c = v[q][j];
@@ -50,7 +51,10 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
     u32 tile_tot = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[w];
-    const u32 excl = seed + (u32)lb2_exclusive_prefix<1>(lb, tile, tile_tot, lane, &hdr->error);
+    // four tile words per lane: the 255 tiles before this one are read directly, which covers nearly every
+    // tile still in flight; with one word per lane most of them came through group words, a hop later
+    // (measured: dense postings +1 ... 3 %, the plain running sum +2 %)
+    const u32 excl = seed + (u32)lb2_exclusive_prefix<4>(lb, tile, tile_tot, lane, &hdr->error);
     if (lane == 0) *s_prefix = excl;
   }
   __syncthreads();
@@ -62,15 +66,22 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
 template <int V, bool ZZ, int NW = kWaves, int NT = 0>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
-    Dir dir, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed) {
+    Dir dir, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed, u64* __restrict__ stamps) {
   __shared__ WaveLds s_lds[NW];
   __shared__ u32 s_wave_tot[NW];
   __shared__ u32 s_prefix;
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
+  const u64 t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // diagnostic build only: 100 MHz wall clock
   if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
   __syncthreads();
   const u32 tile = s_tile;
+  // stamps of a tile: workgroup start, ticket in hand, keys and offsets in, decoded, prefix known, stored
+  auto stamp = [&](int i) {
+    if (stamps && threadIdx.x == 64 * (NW - 1)) stamps[8 * (u64)tile + i] = __builtin_amdgcn_s_memrealtime();
+  };
+  if (stamps && threadIdx.x == 64 * (NW - 1)) stamps[8 * (u64)tile + 0] = t_start;
+  stamp(1);
   WaveLds& S = s_lds[wave];
   const u64 keylen = ((u64)count + 3) >> 2;
   const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
@@ -93,21 +104,50 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
       doff[q] = walk.offset(dir, wt, lane);
     }
   }
+  // Full wave tiles whose 256 keys are all zero (dense posting-list gaps: every value below 256) need no
+  // scan and no LDS -- group j*64+lane is the dword at byte 4*(j*64+lane) of the tile's data (see
+  // decode_wavetile).  Their loads are all sent before any is used: taken one wave tile at a time, as
+  // decode_wavetile would, a wave has 1 KiB in flight per round trip and the whole CU some 20 KiB, and
+  // the kernel is bound by exactly that.
+  if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
+  bool direct[4];  // wave-uniform
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32 wt = wt0 + q;
+    direct[q] = wt < n_wt && (u64)wt * kWtInts + kWtInts <= count && __ballot(w[q] != 0u) == 0ull;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
-    if (wt < n_wt) {
+    if (V == V1234 && direct[q]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[q][j].x = ld_u32(data_base + doff[q] + 4u * (j * 64 + lane));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32 wt = wt0 + q;
+    if (direct[q]) {
+      if (V == V1234) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 d = v[q][j].x;
+          uint4 r = make_uint4(d & 0xFFu, (d >> 8) & 0xFFu, (d >> 16) & 0xFFu, d >> 24);
+          if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
+          v[q][j] = r;
+        }
+      }
+      if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + (V == V1234 ? (u32)kWtInts : 0u);
+    } else if (wt < n_wt) {
       const u64 int0 = (u64)wt * kWtInts;
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
-      const u32 total = decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w[q], nints, data_base + doff[q], lane, S, v[q]);
+      const u32 total = decode_wavetile<V, ZZ, false, false, (NT & kNtLoads) != 0>(w[q], nints, data_base + doff[q], lane, S, v[q]);
       if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + total;
     }
   }
   const u32 wave_tot = wave_running_sums(v, lane);
+  stamp(3);
   const u32 add = tile_value_prefix<NW>(wave_tot, tile, prev, lane, wave, hdr, lb, s_wave_tot,
                                         &s_prefix);
+  stamp(4);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -116,6 +156,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
       r.x += add; r.y += add; r.z += add; r.w += add;
       store_group<(NT & kNtStores) != 0>(out, ((u64)(wt0 + q)) * kWtInts + 4u * (j * 64 + lane), count, r);
     }
+  stamp(5);
 }
 
 // ---------------------------------------------------------------------------

@@ -28,8 +28,8 @@ elif mode == "dense":  # dense postings, delta coded
 else:
     values = gen_width_mix(torch, n, 1, "cuda:0")
 out = torch.empty(svb.streamvbyte_max_compressedbytes(n), dtype=torch.uint8, device="cuda:0")
-if len(sys.argv) > 4:   # encode_pipeline value (2: loads issued a store phase ahead)
-    codec.lib.svbgpu_set_option(b"encode_pipeline", int(sys.argv[4]))
+if len(sys.argv) > 4:   # encode_ticket_early value
+    codec.lib.svbgpu_set_option(b"encode_ticket_early", int(sys.argv[4]))
 for _ in range(3):
     codec.encode(values, out=out, **kw)
 codec.lib.svbgpu_set_option(b"debug_ablate", 16)
