@@ -65,6 +65,18 @@ int svbgpu_device_ok(void);
  *                               look-back overlap the previous tile's stores);
  *                               0: one tile at a time.  Differential encodes
  *                               always take the latter.
+ *   "encode_ticket_early" = -1|0|1  pipelined encoder: 1 asks for a tile's place in
+ *                               the stream one store phase before the tile is
+ *                               loaded, 0 when it is loaded; -1 (default): 1 for
+ *                               0124 (+4 %), 0 for 1234 (1 measured slower)
+ *   "nt_threshold_mib" = n      calls that write at least n MiB (default 128, half
+ *                               the 256 MiB Infinity Cache) store non-temporally;
+ *                               calls that read at least n MiB and touch at least
+ *                               2.5 n MiB load non-temporally (such a stream only
+ *                               sweeps through the cache and evicts what the next
+ *                               call would have found there); -1: never, 0: always
+ *   "nt_force" = -1 | 0..3      -1 (default): by size as above; else bit 0 = loads,
+ *                               bit 1 = stores non-temporal whatever the size
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
  *                               one-tile-at-a-time encoder carries through the
  *                               look-back (default 4)

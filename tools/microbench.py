@@ -161,7 +161,7 @@ if want("batch"):
     dB = float((sizes.sum().item() - ((counts.to(torch.int64) + 3) // 4).sum().item()) / tot)
     ops["batch_encode"] = (lambda: codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=svb.DELTA, sizes=sizes), (4.25 + dB) * tot)
     ops["batch_decode"] = (lambda: codec.decode_batch(bbuf, boff[:-1], back, voff[:-1], counts, None, flags=svb.DELTA, sizes=sizes), (4.25 + dB) * tot)
-    for ch in (0, 8, 16, 32):
+    for ch in (0, 1, 2, 4, 8, 16, 32):
         ops[f"batch_encode_chunk{ch}"] = (opt_with(b"batch_chunk", ch, -1, lambda: codec.encode_batch(vals, voff[:-1], bbuf, boff[:-1], counts, None, flags=svb.DELTA, sizes=sizes)), (4.25 + dB) * tot)
         ops[f"batch_decode_chunk{ch}"] = (opt_with(b"batch_chunk", ch, -1, lambda: codec.decode_batch(bbuf, boff[:-1], back, voff[:-1], counts, None, flags=svb.DELTA, sizes=sizes)), (4.25 + dB) * tot)
 
