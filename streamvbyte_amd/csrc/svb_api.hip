@@ -799,10 +799,13 @@ int svbgpu_encode64(const uint64_t* d_in, uint32_t count, uint8_t* d_out, void* 
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
-  hipLaunchKernelGGL(k_sizes64, dim3(L.n_mega), dim3(1024), 0, S(stream), d_in, count, ws_at<u32>(ws, L.off_wt_rel),
-                     ws_at<u32>(ws, L.off_mega_sum), L.wt_per_mega);
-  hipLaunchKernelGGL(k_encode64, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0, S(stream), d_in, count,
-                     d_out, ws_dir(ws, L), d_written);
+  // the values are read twice, 8 bytes each: beyond the cache, neither pass leaves the other anything to find
+  SVB_NT_SWITCH_01(nt_policy(options(), 8ull * count, 0) ? 1 : 0, NTV, {
+    hipLaunchKernelGGL(k_sizes64<NTV>, dim3(L.n_mega), dim3(1024), 0, S(stream), d_in, count, ws_at<u32>(ws, L.off_wt_rel),
+                       ws_at<u32>(ws, L.off_mega_sum), L.wt_per_mega);
+    hipLaunchKernelGGL(k_encode64<NTV>, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0, S(stream), d_in,
+                       count, d_out, ws_dir(ws, L), d_written);
+  })
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
@@ -820,8 +823,9 @@ int svbgpu_decode64(const uint8_t* d_in, uint64_t* d_out, uint32_t count, void* 
   rc = build_directory(SVBGPU_1248, d_in, count, ws, S(stream));
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
-  hipLaunchKernelGGL(k_decode64, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0, S(stream), d_in, d_out,
-                     count, ws_dir(ws, L), d_consumed);
+  SVB_NT_SWITCH_023(nt_policy(options(), 0, 8ull * count) & kNtStores, NTV,
+                    hipLaunchKernelGGL(k_decode64<NTV>, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0,
+                                       S(stream), d_in, d_out, count, ws_dir(ws, L), d_consumed))
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

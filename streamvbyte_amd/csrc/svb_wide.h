@@ -33,6 +33,7 @@ __device__ __forceinline__ u32 group_len64(u32 key, u32 nv) {
 // k_sizes64: the encoder's directory.  One workgroup of 1024 threads per mega tile;
 // a round takes 16 wave tiles, one per wave (8 loads of 16 bytes per lane), sums the
 // widths, and wave 0 lays the 16 sums behind the mega tile's running offset.
+template <int NT = 0>
 __global__ __launch_bounds__(1024) void k_sizes64(const u64* __restrict__ in, u32 count, u32* __restrict__ wt_rel,
                                                   u32* __restrict__ mega_sum, u32 wt_per_mega) {
   __shared__ u32 s_sum[2][16];
@@ -51,9 +52,8 @@ __global__ __launch_bounds__(1024) void k_sizes64(const u64* __restrict__ in, u3
         const u64 idx = first + 2ull * (64 * i + lane);
         u64 a = 0, b = 0;
         if (idx + 1 < count) {
-          ulonglong2 p;
-          __builtin_memcpy(&p, in + idx, 16);
-          a = p.x; b = p.y;
+          const uint4 p = ld_stream16<(NT & kNtLoads) != 0>(in + idx);
+          a = ((u64)p.y << 32) | p.x; b = ((u64)p.w << 32) | p.z;
           s += (1u << code64(a)) + (1u << code64(b));
         } else if (idx < count) {
           s += 1u << code64(in[idx]);
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(1024) void k_sizes64(const u64* __restrict__ in, u3
 // k_encode64: a wave per wave tile.  Lane l of step s holds group 64 s + l: two 16-byte
 // loads, four width codes, a wave scan of the group lengths, then every value stored at
 // its own byte address in exactly its own length (1, 2, 4 or 8 bytes).
+template <int NT = 0>
 __global__ __launch_bounds__(kBlock) void k_encode64(const u64* __restrict__ in, u32 count, u8* __restrict__ out,
                                                      Dir dir, u64* __restrict__ written) {
   const int lane = lane_id(), wave = wave_id();
@@ -94,10 +95,9 @@ __global__ __launch_bounds__(kBlock) void k_encode64(const u64* __restrict__ in,
     const u32 nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
     u64 v[4] = {0, 0, 0, 0};
     if (nv == 4u) {
-      ulonglong2 p, q;
-      __builtin_memcpy(&p, in + first, 16);
-      __builtin_memcpy(&q, in + first + 2, 16);
-      v[0] = p.x; v[1] = p.y; v[2] = q.x; v[3] = q.y;
+      const uint4 p = ld_stream16<(NT & kNtLoads) != 0>(in + first), q = ld_stream16<(NT & kNtLoads) != 0>(in + first + 2);
+      v[0] = ((u64)p.y << 32) | p.x; v[1] = ((u64)p.w << 32) | p.z;
+      v[2] = ((u64)q.y << 32) | q.x; v[3] = ((u64)q.w << 32) | q.z;
     } else {
       for (u32 k = 0; k < nv; ++k) v[k] = in[first + k];
     }
@@ -147,6 +147,7 @@ __device__ __forceinline__ u64 bytes64_at(const u32 (&d)[8], u32 o, u32 len) {
   const u64 x = ((u64)hi << 32) | lo;
   return len >= 8u ? x : x & ((1ull << (8u * len)) - 1ull);
 }
+template <int NT = 0>
 __global__ __launch_bounds__(kBlock) void k_decode64(const u8* __restrict__ in, u64* __restrict__ out, u32 count,
                                                      Dir dir, u64* __restrict__ consumed) {
   const int lane = lane_id(), wave = wave_id();
@@ -178,10 +179,8 @@ __global__ __launch_bounds__(kBlock) void k_decode64(const u8* __restrict__ in, 
         o += len;
       }
       if (nv == 4u) {
-        ulonglong2 a, b;
-        a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
-        __builtin_memcpy(out + first, &a, 16);
-        __builtin_memcpy(out + first + 2, &b, 16);
+        st_stream16<(NT & kNtStores) != 0>(out + first, make_uint4((u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32)));
+        st_stream16<(NT & kNtStores) != 0>(out + first + 2, make_uint4((u32)v[2], (u32)(v[2] >> 32), (u32)v[3], (u32)(v[3] >> 32)));
       } else {
         for (u32 k = 0; k < nv; ++k) out[first + k] = v[k];
       }
