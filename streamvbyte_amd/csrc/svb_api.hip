@@ -230,18 +230,26 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
   // diagnostic stamps (8 words per tile) live behind the regular workspace when the caller
   // over-allocated it and asked for them
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 64ull * (L.n_wt / 16 + 2) ? ws_at<u64>(ws, L.total) : nullptr;
-  if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
+  if (stamps && V == V1234 && !ZZ && o.scan_waves >= 8) {  // diagnostic instantiations with the stamps compiled in
+    const LbWords lbw{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+    if (o.scan_waves == 16)
+      hipLaunchKernelGGL((k_delta_decode<V1234, false, 16, 3, true>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024), 0, st,
+                         d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws), lbw, d_consumed, stamps);
+    else
+      hipLaunchKernelGGL((k_delta_decode<V1234, false, 8, 3, true>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st,
+                         d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws), lbw, d_consumed, stamps);
+  } else if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16, NTV>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024),
                                          0, st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                                          LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
-                                         d_consumed, stamps))
+                                         d_consumed, (u64*)nullptr))
   else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8, NTV>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0,
                                          st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
                                          LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
-                                         d_consumed, stamps))
+                                         d_consumed, (u64*)nullptr))
   else
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
                      d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
@@ -351,11 +359,14 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2) ? ws_at<u64>(ws, L.total) : nullptr;
   // the ticket a phase early pays for 0124 (short store phases), not for 1234
   const u32 early = o.encode_ticket_early < 0 ? (V == V0124 ? 1u : 0u) : (u32)o.encode_ticket_early;
-  if (full_tiles)
+  if (full_tiles && stamps && !QUANT)  // diagnostic instantiation with the stamps compiled in
+    hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, false, NW, 0, true>), dim3(stream_grid(full_tiles, 2)), dim3(NW * 64), 0,
+                       st, d_in, count, full_tiles, d_out, prev, h, status, d_written, stamps, early);
+  else if (full_tiles)
     SVB_NT_SWITCH_013(nt_policy(o, 4ull * count, min_stream_bytes(V, count)), NTV,
                       hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, QUANT, NW, NTV>), dim3(stream_grid(full_tiles, 2)),
                                          dim3(NW * 64), 0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written,
-                                         stamps, early))
+                                         (u64*)nullptr, early))
   if (ragged)
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, 0u, (u64*)nullptr);

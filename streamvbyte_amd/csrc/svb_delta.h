@@ -63,10 +63,12 @@ __device__ __forceinline__ u32 tile_value_prefix(u32 wave_tot, u32 tile, u32 see
   return add;
 }
 
-template <int V, bool ZZ, int NW = kWaves, int NT = 0>
+// STAMPS: diagnostic build with wall-clock stamps per tile (the product instantiation carries none of it).
+template <int V, bool ZZ, int NW = kWaves, int NT = 0, bool STAMPS = false>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
     const u8* __restrict__ in, u32* __restrict__ out, u32 count, u32 prev,
-    Dir dir, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed, u64* __restrict__ stamps) {
+    Dir dir, WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ consumed, u64* __restrict__ stamps_arg) {
+  u64* const stamps = STAMPS ? stamps_arg : nullptr;
   __shared__ WaveLds s_lds[NW];
   __shared__ u32 s_wave_tot[NW];
   __shared__ u32 s_prefix;

@@ -54,21 +54,19 @@ __device__ __forceinline__ uint4 ld_u128(const u8* p) {
 // of the call -- short streams keep the default policy, their bytes are likely to be used again from
 // the cache by whatever runs next.
 constexpr int kNtLoads = 1, kNtStores = 2;
-// The address need only be 4-byte aligned (values of a batch start at any uint32, a stream's data at any
-// byte for the loads that use ld_stream16 on 16-byte-aligned chunks): the vector type says so.
-typedef u32 u32x4_t __attribute__((ext_vector_type(4), aligned(4)));
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ uint4 ld_stream16(const void* p) {
-  u32x4_t v;
-  if (NT) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-  else v = *reinterpret_cast<const u32x4_t*>(p);
-  return make_uint4(v.x, v.y, v.z, v.w);
+  if (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
 }
 template <bool NT>
 __device__ __forceinline__ void st_stream16(void* p, const uint4& v) {
-  const u32x4_t x = {v.x, v.y, v.z, v.w};
-  if (NT) __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t*>(p));
-  else *reinterpret_cast<u32x4_t*>(p) = x;
+  if (NT) __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+  else *reinterpret_cast<uint4*>(p) = v;
 }
 __device__ __forceinline__ u32 lds_u32(const u8* p) {
   u32 v;

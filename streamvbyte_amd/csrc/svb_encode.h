@@ -519,10 +519,13 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
 // tiles per wave).  Handles only tiles that lie wholly inside the stream; the
 // ragged last tile is a launch of k_encode<.., QW, false, .., NW> on the same
 // look-back words.
-template <int V, bool DELTA, bool ZZ, int QW, bool QUANT = false, int NW = 8, int NT = 0>
+// STAMPS: diagnostic build of the kernel that writes wall-clock stamps per tile (the product instantiation
+// carries none of it: the kernel sits at its register limits and every scalar counts).
+template <int V, bool DELTA, bool ZZ, int QW, bool QUANT = false, int NW = 8, int NT = 0, bool STAMPS = false>
 __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
-    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u64* __restrict__ stamps, u32 early) {
+    WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u64* __restrict__ stamps_arg, u32 early) {
+  u64* const stamps = STAMPS ? stamps_arg : nullptr;
   __shared__ EncWaveLds s_lds[NW];
   __shared__ u32 s_wave_tot[2][NW];
   __shared__ u64 s_prefix;

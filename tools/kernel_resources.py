@@ -2,7 +2,7 @@
 """Print one line per kernel: VGPRs, SGPRs, scratch, LDS, occupancy (hipcc remarks)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + sys.argv[1:] + [ "-I", os.path.join(ROOT, "include"),
        "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null",
        os.path.join(ROOT, "streamvbyte_amd/csrc/svb_api.hip")]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr

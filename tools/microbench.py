@@ -81,7 +81,7 @@ def opt_with(name, value, default, f):
 if want("encode"):
     ops["encode"] = (lambda: codec.encode(values, out=enc_out), (4.25 + dbar) * n)
     ops["encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
-    ops["encode_early"] = (opt_with(b"encode_ticket_early", 1, 0, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_early"] = (opt_with(b"encode_ticket_early", 1, -1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(2, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
 if want("encode_qw"):
     for qw in (1, 2, 4):
@@ -125,7 +125,7 @@ if want("zz"):
     o4 = out[:n4]
     ops["zz0124_encode"] = (lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
     ops["zz0124_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
-    ops["zz0124_encode_early"] = (opt_with(b"encode_ticket_early", 1, 0, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
+    ops["zz0124_encode_early"] = (opt_with(b"encode_ticket_early", 1, -1, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
     ops["zz0124_encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(2, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG))), (4.25 + d4) * n4)
     ops["zz0124_decode"] = (lambda: codec.decode(s4, n4, out=o4, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
 if want("misc"):
