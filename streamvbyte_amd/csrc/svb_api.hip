@@ -192,17 +192,21 @@ int clear_lookback(uint32_t count, void* ws, hipStream_t st) {
 }
 
 // ---- offset directory -------------------------------------------------------
-int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, hipStream_t st) {
+// clear_lb: the launch also zeroes the header and the look-back words (what clear_lookback does), for a
+// differential decode that follows on the same stream.
+int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, hipStream_t st, bool clear_lb = false) {
   const WsLayout L = ws_layout(count);
   u32* wt_rel = ws_at<u32>(ws, L.off_wt_rel);
   u32* mega_sum = ws_at<u32>(ws, L.off_mega_sum);
   const u32 spm = L.wt_per_mega / kSuperWt;
+  u32* clr = clear_lb ? ws_at<u32>(ws, 0) : nullptr;
+  const u32 clr_n = clear_lb ? (u32)(L.off_mega_sum / 4) : 0u;
   if (variant == SVBGPU_1234)
-    hipLaunchKernelGGL(k_key_sums<V1234>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
+    hipLaunchKernelGGL(k_key_sums<V1234>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm, clr, clr_n);
   else if (variant == SVBGPU_1248)
-    hipLaunchKernelGGL(k_key_sums<V1248>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
+    hipLaunchKernelGGL(k_key_sums<V1248>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm, clr, clr_n);
   else
-    hipLaunchKernelGGL(k_key_sums<V0124>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm);
+    hipLaunchKernelGGL(k_key_sums<V0124>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm, clr, clr_n);
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
@@ -273,8 +277,10 @@ void launch_delta_decode2(const Options& o, const uint8_t* d_in, uint32_t* d_out
 }
 
 // decode with the directory already in the workspace
+// lb_cleared: the header and look-back words were zeroed by the directory launch (build_directory(.., true))
 int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_out, uint32_t count,
-               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st, size_t ws_bytes = 0) {
+               uint32_t prev, void* ws, uint64_t* d_consumed, hipStream_t st, size_t ws_bytes = 0,
+               bool lb_cleared = false) {
   const bool zz = flags & SVBGPU_ZIGZAG, delta = flags & SVBGPU_DELTA;
   const bool v0 = variant == SVBGPU_1234;
   if (!delta) {
@@ -283,8 +289,10 @@ int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_i
     else    { if (zz) launch_decode<V0124, true>(o, d_in, d_out, count, ws, d_consumed, st);
               else    launch_decode<V0124, false>(o, d_in, d_out, count, ws, d_consumed, st); }
   } else if (o.delta_lookback) {
-    int rc = clear_lookback(count, ws, st);
-    if (rc) return rc;
+    if (!lb_cleared) {
+      int rc = clear_lookback(count, ws, st);
+      if (rc) return rc;
+    }
     if (v0) { if (zz) launch_delta_decode<V1234, true>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st);
               else    launch_delta_decode<V1234, false>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st); }
     else    { if (zz) launch_delta_decode<V0124, true>(o, d_in, d_out, count, prev, ws, ws_bytes, d_consumed, st);
@@ -482,9 +490,11 @@ int svbgpu_decode(int variant, unsigned flags, const uint8_t* d_in, uint32_t* d_
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  rc = build_directory(variant, d_in, count, ws, S(stream));
+  const Options o = options();
+  const bool fold_clear = (flags & SVBGPU_DELTA) && o.delta_lookback && count > 0;  // one launch fewer
+  rc = build_directory(variant, d_in, count, ws, S(stream), fold_clear);
   if (rc) return rc;
-  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), ws_bytes);
+  return run_decode(o, variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), ws_bytes, fold_clear);
 }
 
 int svbgpu_decode_plan(int variant, const uint8_t* d_in, uint32_t count, void* ws, size_t ws_bytes,
@@ -564,12 +574,14 @@ int svbgpu_decode_static(int variant, unsigned flags, const uint8_t* d_in, uint3
   int rc = static_scratch(&ws);
   if (rc) return rc;
   // Same kernels as svbgpu_decode.  Everything they read from the workspace is
-  // written first by this very call (directory by build_directory; header and
-  // look-back words cleared by run_decode before the look-back decoder), so what
+  // written first by this very call (directory by build_directory, which also clears the header
+  // and look-back words ahead of the look-back decoder), so what
   // the previous call left behind does not matter.
-  rc = build_directory(variant, d_in, count, ws, S(stream));
+  const Options o = options();
+  const bool fold_clear = (flags & SVBGPU_DELTA) && o.delta_lookback;
+  rc = build_directory(variant, d_in, count, ws, S(stream), fold_clear);
   if (rc) return rc;
-  return run_decode(options(), variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream));
+  return run_decode(o, variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), 0, fold_clear);
 }
 
 int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,

@@ -48,11 +48,14 @@ __device__ __forceinline__ u32 row_reduce_scatter16(const u32 (&v)[16], int lane
   return (h4 ? k2[1] : k2[0]) + dpp_get<0x4E>(h4 ? k2[0] : k2[1]);  // quad_perm [2,3,0,1]
 }
 
+// clear / clear_dwords: words this launch also sets to zero (the look-back words of a differential decode
+// that follows on the same stream; a fill launch of their own costs that call 4-5 us).
 template <int V>
 __global__ __launch_bounds__(1024) void k_key_sums(const u8* __restrict__ in, u32 count,
                                                    u32* __restrict__ wt_rel, u32* __restrict__ mega_sum,
-                                                   u32 supers_per_mega) {
+                                                   u32 supers_per_mega, u32* __restrict__ clear, u32 clear_dwords) {
   constexpr int kW = 16;  // waves per workgroup
+  for (u32 i = blockIdx.x * 1024u + threadIdx.x; i < clear_dwords; i += gridDim.x * 1024u) clear[i] = 0u;
   __shared__ u32 s_turn[kW][kSuperWt];
   __shared__ u32 s_tot[2][kW];
   const u64 keylen = ((u64)count + 3) >> 2;
