@@ -385,7 +385,7 @@ void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8
   // Differential coding keeps the larger tiles of k_encode: posting-list gaps are mostly one byte, the
   // store phase is then short, and the pipelined kernel's twice as many tickets (one atomic on one word
   // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
-  if (o.encode_pipeline && !D && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2 && o.encode_waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
@@ -452,7 +452,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
-      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v == 0 || v == 1; }},
+      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 2; }},
       {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
       {"nt_threshold_mib", &o_nt_threshold_mib, [](int v) { return v >= -1; }},
       {"nt_force", &o_nt_force, [](int v) { return v >= -1 && v <= 3; }},

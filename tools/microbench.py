@@ -94,7 +94,7 @@ if want("delta"):
     s3 = s3.clone()
     d3 = (int(z3.item()) - keylen) / n
     ops["delta_encode"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
-    ops["delta_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
+    ops["delta_encode_pipe"] = (opt_with(b"encode_pipeline", 2, 1, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
     ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
 
     ops["delta_decode_w8"] = (opt_with(b"scan_waves", 8, 16, lambda: codec.decode(s3, n, out=out, flags=svb.DELTA)), (4.25 + d3) * n)
@@ -105,7 +105,7 @@ if want("delta"):
         codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
     ops["delta_decode_twopass"] = (dd_twopass, (4.25 + d3) * n)
     ops["delta_encode_mixed"] = (lambda: codec.encode(values, out=enc_out, flags=svb.DELTA), (4.25 + dbar) * n)
-    ops["delta_encode_mixed_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(values, out=enc_out, flags=svb.DELTA)), (4.25 + dbar) * n)
+    ops["delta_encode_mixed_pipe"] = (opt_with(b"encode_pipeline", 2, 1, lambda: codec.encode(values, out=enc_out, flags=svb.DELTA)), (4.25 + dbar) * n)
     sm, zm = codec.encode(values, flags=svb.DELTA)
     sm = sm.clone()
     ops["delta_decode_mixed"] = (lambda: codec.decode(sm, n, out=out, flags=svb.DELTA), (int(zm.item()) + 4.0 * n))
