@@ -172,6 +172,29 @@ def test_cache_policies_and_early_ticket(torch_mod, codec, oracle):
         lib.svbgpu_set_option(b"encode_ticket_early", -1)
 
 
+def test_differential_encode_through_every_encoder(torch_mod, codec, oracle):
+    """encode_pipeline 0 / 1 / 2: differential input through the tile-at-a-time kernel and through the
+    pipelined one gives the oracle's bytes (dense gaps, mixed gaps, zigzag, both variants, prev != 0)."""
+    from streamvbyte_amd import DELTA, ZIGZAG
+    lib = codec.lib
+    try:
+        for i, n in enumerate([5, 16385, 65536 + 3, (1 << 20) + 7, (1 << 22) + 1]):
+            dense = np.cumsum(np.random.default_rng(7100 + i).integers(0, 32, n, dtype=np.uint64)).astype(np.uint32)
+            for v in (dense, gen("width_mix", n, 7200 + i)):
+                d_v = to_dev(torch_mod, v)
+                for mode in (0, 1, 2):
+                    assert lib.svbgpu_set_option(b"encode_pipeline", mode) == 0
+                    for variant, flags, prev in ((V1234, DELTA, 77), (V0124, DELTA, 0), (V1234, DELTA | ZIGZAG, 5)):
+                        src = oracle.zigzag_delta_encode(v.view(np.int32), prev) if flags & ZIGZAG else v
+                        expect = oracle.encode(variant, src, not (flags & ZIGZAG), prev)
+                        out, size = codec.encode(d_v, variant=variant, flags=flags, prev=prev)
+                        codec.check()
+                        assert int(size.item()) == expect.size, (n, mode, variant, flags)
+                        assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, mode, variant, flags)
+    finally:
+        lib.svbgpu_set_option(b"encode_pipeline", 1)
+
+
 def test_size_and_validate(torch_mod, codec, oracle):
     for i, n in enumerate(SIZES):
         v = gen("perf_c", n, 5000 + i)
