@@ -159,6 +159,12 @@ inline int nt_policy(const Options& o, unsigned long long load_bytes, unsigned l
   const bool loads = load_bytes >= t && 2 * (load_bytes + store_bytes) >= 5 * t;
   return (loads ? kNtLoads : 0) | (stores ? kNtStores : 0);
 }
+// Batched calls choose on the device (batch_nt_policy): the host hands over the forced policy or -1 and
+// the threshold in bytes.
+inline int batch_nt_force(const Options& o) { return o.nt_force >= 0 ? o.nt_force : (o.nt_threshold_mib < 0 ? 0 : -1); }
+inline unsigned long long batch_nt_bytes(const Options& o) {
+  return o.nt_threshold_mib < 0 ? 0 : (unsigned long long)o.nt_threshold_mib << 20;
+}
 // Least size of a stream of `count` values: the keys plus one byte per value (1234) or nothing (0124).
 inline unsigned long long min_stream_bytes(int v, unsigned long long count) {
   return (count + 3) / 4 + (v == V1234 ? count : 0);
@@ -882,7 +888,7 @@ int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t* d_values,
   const Options o = options();
   const unsigned grid = batch_grid(o, nstreams);
   DISPATCH_VDZ(launch_encode_batch, variant, flags, grid, batch_chunk(o, nstreams, 8), d_values, d_value_off, d_bytes, d_byte_off,
-               d_counts, d_prev, nstreams, d_sizes, S(stream));
+               d_counts, d_prev, nstreams, d_sizes, batch_nt_force(o), batch_nt_bytes(o), S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
@@ -897,7 +903,7 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, con
   const Options o = options();
   const unsigned grid = batch_grid(o, nstreams);
   DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, batch_chunk(o, nstreams, 32), d_bytes, d_byte_off, d_values, d_value_off,
-               d_counts, d_prev, nstreams, d_sizes, S(stream));
+               d_counts, d_prev, nstreams, d_sizes, batch_nt_force(o), batch_nt_bytes(o), S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

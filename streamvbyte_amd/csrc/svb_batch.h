@@ -307,17 +307,35 @@ __device__ __forceinline__ FlatSlot flat_slot(u32 base, u32 n_slots, u32 n_short
   return s;
 }
 
+// Cache policy of a batched call, chosen on the DEVICE: the directory lives in device memory, so the host
+// does not know how many bytes a batch moves.  Every wavefront takes the extent of the value array from
+// the first and the last directory entry (three uniform loads that hit in cache) and applies the rule the
+// single-stream calls apply on the host: non-temporal stores from `nt_bytes` written, loads as well when
+// the input is that long and the footprint passes 2.5 x nt_bytes; the streams count with the least size
+// they can have.  It is a policy only: a directory that is not laid out in order gets a wrong guess and
+// the same results.  nt_force >= 0 (options nt_force, or 0 when the policy is off) skips the guess.
+template <int V>
+__device__ __forceinline__ int batch_nt_policy(int nt_force, u64 nt_bytes, const u64* __restrict__ value_off,
+                                               const u32* __restrict__ counts, u32 nstreams, bool encode) {
+  if (nt_force >= 0) return nt_force;
+  const u64 v0 = value_off[0], v1 = value_off[nstreams - 1] + counts[nstreams - 1];
+  const u64 nvals = v1 > v0 ? v1 - v0 : v0 - v1;
+  const u64 vbytes = 4 * nvals, sbytes = ((nvals + 3) >> 2) + (V == V1234 ? nvals : 0);
+  const u64 ld = encode ? vbytes : sbytes, st = encode ? sbytes : vbytes;
+  return (ld >= nt_bytes && 2 * (ld + st) >= 5 * nt_bytes ? kNtLoads : 0) | (st >= nt_bytes ? kNtStores : 0);
+}
+
 // Blocks [0, n_long_blocks) work off the LONG streams, K_long of the batch's streams per wavefront;
 // the blocks behind them the FLAT part, 64 streams per wavefront (few streams per wavefront keep the
 // long-running wavefronts similar in length and the launch's tail short; many keep the flat steps full).
-template <int V, bool DELTA, bool ZZ>
-__global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
+// NT: bit 0 the streams' data bytes of the long part, bit 1 the values (see ld_stream16 / st_stream16).
+template <int V, bool DELTA, bool ZZ, int NT>
+__device__ __forceinline__ void decode_batch2_body(
     const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
     const u64* __restrict__ value_off, const u32* __restrict__ counts,
-    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks) {
-  __shared__ WaveLds s_lds[kBatchWaves];
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks,
+    WaveLds& S) {
   const int lane = lane_id(), wave = wave_id();
-  WaveLds& S = s_lds[wave];
   const bool flat_role = blockIdx.x >= n_long_blocks;
   const u32 K = flat_role ? 64u : K_long;
   const u64 s0 = ((u64)(flat_role ? blockIdx.x - n_long_blocks : blockIdx.x) * kBatchWaves + wave) * K;
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
         c.x += ex; c.y += ex; c.z += ex; c.w += ex;
       }
       if (f.have) {
-        store_group(values + f.e.voff, 4ull * f.gi, f.e.cnt, c);
+        store_group<(NT & kNtStores) != 0>(values + f.e.voff, 4ull * f.gi, f.e.cnt, c);
         if (sizes && f.gi == keylen - 1u) sizes[f.e.sid] = (u64)keylen + incl;
       }
       carry_idx = (u32)__builtin_amdgcn_readlane((int)f.idx, 63);
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
       const u64 int0 = (u64)wt * kWtInts;
       const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
       uint4 v[4];
-      doff += decode_wavetile<V, ZZ>(w, nints, in + keylen + doff, lane, S, v);
+      doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, nints, in + keylen + doff, lane, S, v);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint4 c = v[j];
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
           run += wave_last(incl);
           c.x += ex; c.y += ex; c.z += ex; c.w += ex;
         }
-        store_group(out, int0 + 4u * (j * 64 + lane), count, c);
+        store_group<(NT & kNtStores) != 0>(out, int0 + 4u * (j * 64 + lane), count, c);
       }
     }
     if (sizes && lane == 0) sizes[s0 + src] = keylen + doff;
@@ -415,13 +433,30 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
 }
 
 template <int V, bool DELTA, bool ZZ>
-__global__ __launch_bounds__(64 * kBatchWaves) void k_encode_batch2(
+__global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
+    const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
+    const u64* __restrict__ value_off, const u32* __restrict__ counts,
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks,
+    int nt_force, u64 nt_bytes) {
+  __shared__ WaveLds s_lds[kBatchWaves];
+  WaveLds& S = s_lds[wave_id()];
+  const int nt = batch_nt_policy<V>(nt_force, nt_bytes, value_off, counts, nstreams, false);
+  if (nt == 3)
+    decode_batch2_body<V, DELTA, ZZ, 3>(bytes, byte_off, values, value_off, counts, prevs, nstreams, sizes, K_long, n_long_blocks, S);
+  else if (nt == 2)
+    decode_batch2_body<V, DELTA, ZZ, 2>(bytes, byte_off, values, value_off, counts, prevs, nstreams, sizes, K_long, n_long_blocks, S);
+  else
+    decode_batch2_body<V, DELTA, ZZ, 0>(bytes, byte_off, values, value_off, counts, prevs, nstreams, sizes, K_long, n_long_blocks, S);
+}
+
+// NT: bit 0 the values, bit 1 the streams' bytes of the long part.
+template <int V, bool DELTA, bool ZZ, int NT>
+__device__ __forceinline__ void encode_batch2_body(
     const u32* __restrict__ values, const u64* __restrict__ value_off, u8* __restrict__ bytes,
     const u64* __restrict__ byte_off, const u32* __restrict__ counts,
-    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks) {
-  __shared__ EncWaveLds s_lds[kBatchWaves];
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks,
+    EncWaveLds& S) {
   const int lane = lane_id(), wave = wave_id();
-  EncWaveLds& S = s_lds[wave];
   const bool flat_role = blockIdx.x >= n_long_blocks;  // as in k_decode_batch2
   const u32 K = flat_role ? 64u : K_long;
   const u64 s0 = ((u64)(flat_role ? blockIdx.x - n_long_blocks : blockIdx.x) * kBatchWaves + wave) * K;
@@ -452,7 +487,7 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_encode_batch2(
     const u32 keylen = (f.e.cnt + 3u) >> 2;
     const u32 lim = f.have ? f.e.cnt : 0u;
     const u32 nv = f.have ? min(4u, f.e.cnt - 4u * f.gi) : 0u;
-    uint4 c = load_group(in, 4ull * f.gi, lim);
+    uint4 c = load_group<(NT & kNtLoads) != 0>(in, 4ull * f.gi, lim);
     if (DELTA) {
       u32 p = f.e.prev;  // the value before the group's first: the stream's seed or the stream's own value
       if (f.have && f.gi) p = in[4u * f.gi - 1u];
@@ -506,7 +541,7 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_encode_batch2(
       uint4 x[4];
       u32 g[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = load_group(in, int0 + 4u * (j * 64 + lane), count);
+      for (int j = 0; j < 4; ++j) x[j] = load_group<(NT & kNtLoads) != 0>(in, int0 + 4u * (j * 64 + lane), count);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint4 c = x[j];
@@ -521,23 +556,38 @@ __global__ __launch_bounds__(64 * kBatchWaves) void k_encode_batch2(
         x[j] = c;
         g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
       }
-      doff += encode_wavetile<V, false>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
+      doff += encode_wavetile<V, false, (NT & kNtStores) != 0>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
     }
     if (lane == 0) sizes[s0 + src] = keylen + doff;
   }
+}
+
+template <int V, bool DELTA, bool ZZ>
+__global__ __launch_bounds__(64 * kBatchWaves) void k_encode_batch2(
+    const u32* __restrict__ values, const u64* __restrict__ value_off, u8* __restrict__ bytes,
+    const u64* __restrict__ byte_off, const u32* __restrict__ counts,
+    const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks,
+    int nt_force, u64 nt_bytes) {
+  __shared__ EncWaveLds s_lds[kBatchWaves];
+  EncWaveLds& S = s_lds[wave_id()];
+  // both or neither: loads alone measured slower than the default policy on a batch of posting lists
+  if (batch_nt_policy<V>(nt_force, nt_bytes, value_off, counts, nstreams, true) == 3)
+    encode_batch2_body<V, DELTA, ZZ, 3>(values, value_off, bytes, byte_off, counts, prevs, nstreams, sizes, K_long, n_long_blocks, S);
+  else
+    encode_batch2_body<V, DELTA, ZZ, 0>(values, value_off, bytes, byte_off, counts, prevs, nstreams, sizes, K_long, n_long_blocks, S);
 }
 
 template <int V, bool D, bool Z>
 void launch_decode_batch(unsigned grid, unsigned chunk, const uint8_t* d_bytes, const uint64_t* d_byte_off,
                          uint32_t* d_values, const uint64_t* d_value_off, const uint32_t* d_counts,
                          const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes,
-                         hipStream_t st) {
+                         int nt_force, unsigned long long nt_bytes, hipStream_t st) {
   if (chunk) {  // chunked kernel: long streams `chunk` of the batch's streams per wavefront, then the flat part
     const unsigned long long long_blocks = (((unsigned long long)nstreams + chunk - 1) / chunk + kBatchWaves - 1) / kBatchWaves;
     const unsigned long long flat_blocks = (((unsigned long long)nstreams + 63) / 64 + kBatchWaves - 1) / kBatchWaves;
     hipLaunchKernelGGL((k_decode_batch2<V, D, Z>), dim3((unsigned)(long_blocks + flat_blocks)), dim3(64 * kBatchWaves), 0, st,
                        d_bytes, d_byte_off, d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes, chunk,
-                       (unsigned)long_blocks);
+                       (unsigned)long_blocks, nt_force, (u64)nt_bytes);
     return;
   }
   // short lists, four to a wavefront; then the long ones, one wavefront each
@@ -551,13 +601,13 @@ template <int V, bool D, bool Z>
 void launch_encode_batch(unsigned grid, unsigned chunk, const uint32_t* d_values, const uint64_t* d_value_off,
                          uint8_t* d_bytes, const uint64_t* d_byte_off, const uint32_t* d_counts,
                          const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes,
-                         hipStream_t st) {
+                         int nt_force, unsigned long long nt_bytes, hipStream_t st) {
   if (chunk) {
     const unsigned long long long_blocks = (((unsigned long long)nstreams + chunk - 1) / chunk + kBatchWaves - 1) / kBatchWaves;
     const unsigned long long flat_blocks = (((unsigned long long)nstreams + 63) / 64 + kBatchWaves - 1) / kBatchWaves;
     hipLaunchKernelGGL((k_encode_batch2<V, D, Z>), dim3((unsigned)(long_blocks + flat_blocks)), dim3(64 * kBatchWaves), 0, st,
                        d_values, d_value_off, d_bytes, d_byte_off, d_counts, d_prev, nstreams, d_sizes, chunk,
-                       (unsigned)long_blocks);
+                       (unsigned)long_blocks, nt_force, (u64)nt_bytes);
     return;
   }
   const unsigned rows_grid = (unsigned)std::min<unsigned long long>(grid, ((unsigned long long)nstreams + 15) / 16);

@@ -26,10 +26,12 @@ struct __align__(16) EncWaveLds {
 };
 
 // Load the 4 values of the group starting at value index `first`, with bounds.
+template <bool NTL = false>
 __device__ __forceinline__ uint4 load_group(const u32* __restrict__ in, u64 first, u32 count) {
   uint4 x = make_uint4(0, 0, 0, 0);
   if (first + 4 <= count) {
-    __builtin_memcpy(&x, in + first, 16);
+    if (NTL) x = ld_stream16<true>(in + first);
+    else __builtin_memcpy(&x, in + first, 16);
   } else if (first < count) {
     x.x = in[first];
     if (first + 1 < count) x.y = in[first + 1];

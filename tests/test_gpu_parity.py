@@ -344,6 +344,49 @@ def test_batched_flag_combinations(torch_mod, codec, oracle, variant, flagbits):
     assert np.array_equal(to_np(back, np.uint32), values)
 
 
+def test_batched_cache_policies(torch_mod, codec, oracle):
+    """Batched calls under every forced cache policy, and with the choice left to the device at a
+    threshold (0 and 1 MiB) that this batch crosses: the same bytes and integers."""
+    from streamvbyte_amd import DELTA, ZIGZAG, streamvbyte_max_compressedbytes
+    torch = torch_mod
+    lib = codec.lib
+    rng = np.random.default_rng(4242)
+    ns = 1500
+    counts = np.floor(np.exp(rng.uniform(0, np.log(4096), size=ns))).astype(np.uint32)
+    counts[:7] = [0, 1, 256, 257, 1024, 1025, 9000]
+    counts[-1] = 0  # the device's guess reads the last directory entry
+    prevs = rng.integers(0, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)
+    voff = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    cap = np.array([streamvbyte_max_compressedbytes(int(c)) for c in counts], dtype=np.uint64)
+    boff = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+    values = np.concatenate([GENERATORS["postings" if k % 2 else "width_mix"](rng, int(c)) for k, c in enumerate(counts)])
+    assert values.size * 4 > (2 << 20)
+    d_values = to_dev(torch, values)
+    d_voff = torch.from_numpy(voff[:-1].astype(np.int64)).cuda()
+    d_boff = torch.from_numpy(boff[:-1].astype(np.int64)).cuda()
+    d_counts, d_prevs = to_dev(torch, counts), to_dev(torch, prevs)
+    try:
+        for variant, flags in ((V1234, DELTA), (V0124, ZIGZAG), (V1234, 0)):
+            expect = [_expected_stream(oracle, variant, flags, values[int(voff[s]): int(voff[s + 1])],
+                                       int(prevs[s]) if flags & DELTA else 0) for s in range(ns)]
+            for force, mib in ((0, 128), (1, 128), (2, 128), (3, 128), (-1, 0), (-1, 1), (-1, 128)):
+                assert lib.svbgpu_set_option(b"nt_force", force) == 0
+                assert lib.svbgpu_set_option(b"nt_threshold_mib", mib) == 0
+                buf = torch.zeros(int(boff[-1]) + 16, dtype=torch.uint8, device="cuda:0")
+                sizes = codec.encode_batch(d_values, d_voff, buf, d_boff, d_counts, d_prevs, variant=variant, flags=flags)
+                h_sizes, h_buf = sizes.cpu().numpy(), buf.cpu().numpy()
+                for s in range(ns):
+                    assert h_sizes[s] == expect[s].size, (s, counts[s], force, mib)
+                    assert np.array_equal(h_buf[int(boff[s]): int(boff[s]) + expect[s].size], expect[s]), (s, counts[s], force, mib)
+                back = torch.zeros_like(d_values)
+                used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+                assert np.array_equal(used.cpu().numpy(), h_sizes), (force, mib)
+                assert np.array_equal(to_np(back, np.uint32), values), (force, mib)
+    finally:
+        lib.svbgpu_set_option(b"nt_force", -1)
+        lib.svbgpu_set_option(b"nt_threshold_mib", 128)
+
+
 def test_calls_capture_into_a_hip_graph(torch_mod, codec, oracle):
     """The device API allocates nothing and never synchronises, so a sequence of
     calls records into a HIP graph and replays on new data in the same buffers."""

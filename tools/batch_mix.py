@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Batched encode / decode of the posting-list mix (lists of log-uniform length 1..4096) under
-different grids: python tools/batch_mix.py [lists_per_wave ...]   (0 = persistent grid)"""
+different grids: python tools/batch_mix.py [lists_per_wave ...]   (0 = persistent grid)
+SVB_NT_FORCE=<0..3> in the environment forces a cache policy (default: the library's own choice)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +27,7 @@ boff = torch.from_numpy(np.concatenate([[0], np.cumsum(cap)])[:-1]).to(dev)
 bbuf = torch.empty(int(cap.sum()) + 16, dtype=torch.uint8, device=dev)
 back = torch.empty_like(vals)
 codec = svb.DeviceCodec(1 << 20, dev)
+codec.lib.svbgpu_set_option(b"nt_force", int(os.environ.get("SVB_NT_FORCE", "-1")))
 sizes = codec.encode_batch(vals, voff, bbuf, boff, counts, None, flags=svb.DELTA)
 ab = 4.0 * n + float(sizes.sum().item())
 
