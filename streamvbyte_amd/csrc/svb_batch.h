@@ -412,12 +412,8 @@ __device__ __forceinline__ void decode_batch2_body(
       const u32 w = w_next;
       if (wt + 1 < n_wt) w_next = load_keys(wt + 1);  // the next wave tile's keys travel meanwhile
       const u64 int0 = (u64)wt * kWtInts;
-      const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
       uint4 v[4];
-      doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, nints, in + keylen + doff, lane, S, v);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint4 c = v[j];
+      auto integrate = [&](uint4 c) -> uint4 {  // differences -> values, `run` carried along
         if (DELTA) {
           c.y += c.x; c.z += c.y; c.w += c.z;
           const u32 incl = wave_scan_incl(c.w, lane);
@@ -425,7 +421,23 @@ __device__ __forceinline__ void decode_batch2_body(
           run += wave_last(incl);
           c.x += ex; c.y += ex; c.z += ex; c.w += ex;
         }
-        store_group<(NT & kNtStores) != 0>(out, int0 + 4u * (j * 64 + lane), count, c);
+        return c;
+      };
+      if (int0 + kWtInts <= count) {
+        // a whole wave tile (wave-uniform): the length is a constant, so every bounds check of the
+        // tile decoder and of the stores folds away
+        doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, (u32)kWtInts, in + keylen + doff, lane, S, v);
+        u32* o = out + int0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st_stream16<(NT & kNtStores) != 0>(o + 4u * (u32)(j * 64 + lane), integrate(v[j]));
+      } else {
+        const u32 nints = (u32)((u64)count - int0);
+        doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, nints, in + keylen + doff, lane, S, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (256u * j >= nints) break;  // wave-uniform: the stream's last wave tile ends before this quarter
+          store_group<(NT & kNtStores) != 0>(out, int0 + 4u * (j * 64 + lane), count, integrate(v[j]));
+        }
       }
     }
     if (sizes && lane == 0) sizes[s0 + src] = keylen + doff;
@@ -537,26 +549,46 @@ __device__ __forceinline__ void encode_batch2_body(
     u64 doff = 0;
     for (u32 wt = 0; wt < n_wt; ++wt) {
       const u64 int0 = (u64)wt * kWtInts;
-      const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
       uint4 x[4];
       u32 g[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = load_group<(NT & kNtLoads) != 0>(in, int0 + 4u * (j * 64 + lane), count);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint4 c = x[j];
+      auto differences = [&](uint4 c) -> uint4 {  // values -> what gets coded, `carry` carried along
         if (DELTA) {
           const u32 p = wave_shift_up1(c.w, carry);
           carry = wave_last(c.w);
           c = make_uint4(c.x - p, c.y - c.x, c.z - c.y, c.w - c.z);
         }
         if (ZZ) c = make_uint4(zz_enc(c.x), zz_enc(c.y), zz_enc(c.z), zz_enc(c.w));
-        const u64 first = int0 + 4u * (j * 64 + lane);
-        if (DELTA || ZZ) zero_absent(c, first, count);
-        x[j] = c;
-        g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
+        return c;
+      };
+      if (int0 + kWtInts <= count) {
+        // a whole wave tile (wave-uniform): unconditional loads, and the tile encoder of the
+        // single-stream kernels for full tiles (keys first, lengths from the four keys of a lane at once)
+        const u32* src = in + int0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = ld_stream16<(NT & kNtLoads) != 0>(src + 4u * (u32)(j * 64 + lane));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = differences(x[j]);
+        u32 k4 = classify_key<V>(x[0]) | (classify_key<V>(x[1]) << 8) | (classify_key<V>(x[2]) << 16) |
+                 (classify_key<V>(x[3]) << 24);
+        asm volatile("" : "+v"(k4));  // the four keys stay in one register
+        const u32 lens4 = key_lens4<V>(k4, 16u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = ((k4 >> (8 * j)) & 0xFFu) | (((lens4 >> (8 * j)) & 0xFFu) << 24);
+        doff += encode_wavetile<V, true, (NT & kNtStores) != 0>(x, g, (u32)kWtInts, lane, S, out + keylen + doff, out + (int0 >> 2));
+      } else {
+        const u32 nints = (u32)((u64)count - int0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = load_group<(NT & kNtLoads) != 0>(in, int0 + 4u * (j * 64 + lane), count);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint4 c = differences(x[j]);
+          const u64 first = int0 + 4u * (j * 64 + lane);
+          if (DELTA || ZZ) zero_absent(c, first, count);
+          x[j] = c;
+          g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
+        }
+        doff += encode_wavetile<V, false, (NT & kNtStores) != 0>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
       }
-      doff += encode_wavetile<V, false, (NT & kNtStores) != 0>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
     }
     if (lane == 0) sizes[s0 + src] = keylen + doff;
   }
