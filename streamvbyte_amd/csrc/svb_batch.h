@@ -445,7 +445,7 @@ __device__ __forceinline__ void decode_batch2_body(
 }
 
 template <int V, bool DELTA, bool ZZ>
-__global__ __launch_bounds__(64 * kBatchWaves) void k_decode_batch2(
+__global__ __launch_bounds__(64 * kBatchWaves, 7) void k_decode_batch2(
     const u8* __restrict__ bytes, const u64* __restrict__ byte_off, u32* __restrict__ values,
     const u64* __restrict__ value_off, const u32* __restrict__ counts,
     const u32* __restrict__ prevs, u32 nstreams, u64* __restrict__ sizes, u32 K_long, u32 n_long_blocks,
