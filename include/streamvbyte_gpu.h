@@ -76,7 +76,11 @@ int svbgpu_device_ok(void);
  *                               calls that read at least n MiB and touch at least
  *                               2.5 n MiB load non-temporally (such a stream only
  *                               sweeps through the cache and evicts what the next
- *                               call would have found there); -1: never, 0: always
+ *                               call would have found there); -1: never, 0: always.
+ *                               Batched calls apply the rule on the device to the
+ *                               extent of the value array between the first and the
+ *                               last directory entry (the host does not see their
+ *                               sizes)
  *   "nt_force" = -1 | 0..3      -1 (default): by size as above; else bit 0 = loads,
  *                               bit 1 = stores non-temporal whatever the size
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
