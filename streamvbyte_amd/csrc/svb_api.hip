@@ -169,6 +169,16 @@ inline unsigned long long batch_nt_bytes(const Options& o) {
 inline unsigned long long min_stream_bytes(int v, unsigned long long count) {
   return (count + 3) / 4 + (v == V1234 ? count : 0);
 }
+// The encoders' form of the rule: their input also loads non-temporally once it is as large as the cache
+// itself (2 x the threshold), whatever they write -- an encoder gains nothing from cached input (it is not
+// bound by its reads), and 0124 streams are too short to lift the footprint over the general rule's mark
+// (2^26 gradients, 256 MiB in and 20 MiB out: 0.422 -> 0.433 of peak; at half that size it loses 3 %).
+inline int nt_policy_encode(const Options& o, int v, unsigned long long count) {
+  int nt = nt_policy(o, 4ull * count, min_stream_bytes(v, count));
+  if (o.nt_force < 0 && o.nt_threshold_mib >= 0 && 4ull * count >= ((unsigned long long)o.nt_threshold_mib << 21))
+    nt |= kNtLoads;
+  return nt;
+}
 
 inline WsHeader* ws_hdr(void* ws) { return reinterpret_cast<WsHeader*>(ws); }
 template <class T>
@@ -348,7 +358,7 @@ void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, ui
                     ? ws_at<u64>(ws, L.total) : nullptr;
   const unsigned grid = stream_grid(full_tiles, NW == 8 ? (QW <= 2 ? 3 : 2) : (QW > 2 || V != V1234 ? 4 : 5));
   if (full_tiles && QW == 4)  // the shapes in regular use take the non-temporal policy of the call
-    SVB_NT_SWITCH_013(nt_policy(o, 4ull * count, min_stream_bytes(V, count)), NTV,
+    SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
                       hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW, (QW == 4 ? NTV : 0)>), dim3(grid), dim3(NW * 64), 0,
                                          st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps))
   else if (full_tiles)
@@ -377,7 +387,7 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
     hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, false, NW, 0, true>), dim3(stream_grid(full_tiles, 2)), dim3(NW * 64), 0,
                        st, d_in, count, full_tiles, d_out, prev, h, status, d_written, stamps, early);
   else if (full_tiles)
-    SVB_NT_SWITCH_013(nt_policy(o, 4ull * count, min_stream_bytes(V, count)), NTV,
+    SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
                       hipLaunchKernelGGL((k_encode_pipe<V, D, Z, QW, QUANT, NW, NTV>), dim3(stream_grid(full_tiles, 2)),
                                          dim3(NW * 64), 0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written,
                                          (u64*)nullptr, early))
