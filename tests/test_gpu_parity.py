@@ -387,6 +387,45 @@ def test_batched_cache_policies(torch_mod, codec, oracle):
         lib.svbgpu_set_option(b"nt_threshold_mib", 128)
 
 
+def test_batched_directory_in_any_order(torch_mod, codec, oracle):
+    """The directory of a batch need not follow the memory layout: streams listed in reverse and in
+    shuffled order (the device's guess at the batch's size, taken from the first and last entry, is then
+    wrong or even 'negative') give the same bytes per stream; a batch of one stream too."""
+    from streamvbyte_amd import DELTA, streamvbyte_max_compressedbytes
+    torch = torch_mod
+    lib = codec.lib
+    rng = np.random.default_rng(777)
+    ns = 600
+    counts = np.floor(np.exp(rng.uniform(0, np.log(4096), size=ns))).astype(np.uint32)
+    prevs = rng.integers(0, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)
+    voff = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    cap = np.array([streamvbyte_max_compressedbytes(int(c)) for c in counts], dtype=np.uint64)
+    boff = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+    values = np.concatenate([GENERATORS["postings"](rng, int(c)) for c in counts])
+    expect = [oracle.encode(V1234, values[int(voff[s]): int(voff[s + 1])], True, int(prevs[s])) for s in range(ns)]
+    d_values = to_dev(torch, values)
+    try:
+        assert lib.svbgpu_set_option(b"nt_threshold_mib", 0) == 0  # the guess decides something at this size
+        for order in (np.arange(ns)[::-1].copy(), rng.permutation(ns), np.array([ns // 2])):
+            d_voff = torch.from_numpy(voff[:-1][order].astype(np.int64)).cuda()
+            d_boff = torch.from_numpy(boff[:-1][order].astype(np.int64)).cuda()
+            d_counts, d_prevs = to_dev(torch, counts[order]), to_dev(torch, prevs[order])
+            buf = torch.zeros(int(boff[-1]) + 16, dtype=torch.uint8, device="cuda:0")
+            sizes = codec.encode_batch(d_values, d_voff, buf, d_boff, d_counts, d_prevs, variant=V1234, flags=DELTA)
+            h_sizes, h_buf = sizes.cpu().numpy(), buf.cpu().numpy()
+            for k, s in enumerate(order):
+                assert h_sizes[k] == expect[s].size, (k, s)
+                assert np.array_equal(h_buf[int(boff[s]): int(boff[s]) + expect[s].size], expect[s]), (k, s)
+            back = torch.zeros_like(d_values)
+            used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=V1234, flags=DELTA)
+            assert np.array_equal(used.cpu().numpy(), h_sizes)
+            h_back = to_np(back, np.uint32)
+            for s in order:
+                assert np.array_equal(h_back[int(voff[s]): int(voff[s + 1])], values[int(voff[s]): int(voff[s + 1])]), s
+    finally:
+        lib.svbgpu_set_option(b"nt_threshold_mib", 128)
+
+
 def test_calls_capture_into_a_hip_graph(torch_mod, codec, oracle):
     """The device API allocates nothing and never synchronises, so a sequence of
     calls records into a HIP graph and replays on new data in the same buffers."""
