@@ -329,8 +329,8 @@ int run_decode(const Options& o, int variant, unsigned flags, const uint8_t* d_i
 // work.  0 = such a persistent grid.  See svbgpu_set_option.
 // Streams of the batch per wavefront in the long-stream blocks of the chunked batch kernels: `most` when
 // the batch is large enough to give every CU some 32 wavefronts that way (measured best on a million
-// posting lists: 32 for the decoder, 8 for the encoder), fewer for smaller batches so that the device still
-// fills.
+// posting lists: 16 for the decoder -- 32 before its key loads ran ahead across streams --, 8 for the encoder),
+// fewer for smaller batches so that the device still fills.
 inline unsigned batch_chunk(const Options& o, uint32_t nstreams, unsigned most) {
   if (o.batch_chunk >= 0) return (unsigned)o.batch_chunk;
   const unsigned long long want_waves = (unsigned long long)(dev_info().cus ? dev_info().cus : 256) * 32;
@@ -912,7 +912,7 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, con
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   const Options o = options();
   const unsigned grid = batch_grid(o, nstreams);
-  DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, batch_chunk(o, nstreams, 32), d_bytes, d_byte_off, d_values, d_value_off,
+  DISPATCH_VDZ(launch_decode_batch, variant, flags, grid, batch_chunk(o, nstreams, 16), d_bytes, d_byte_off, d_values, d_value_off,
                d_counts, d_prev, nstreams, d_sizes, batch_nt_force(o), batch_nt_bytes(o), S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;

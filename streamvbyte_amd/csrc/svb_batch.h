@@ -388,59 +388,90 @@ __device__ __forceinline__ void decode_batch2_body(
   }
 
   // ---- long streams, one after the other, the whole wavefront on a wave tile at a time ----
+  // One loop over (stream, wave tile) items with ONE key load per round, issued at one place: the keys
+  // of the item after the current one, which is the stream's next wave tile or the first wave tile of the
+  // chunk's next long stream, travel while the current item is decoded and stored.  The load is
+  // unconditional (lanes past the keys re-read the last key dword; the tile decoder masks what lies past
+  // the tile's values anyway), so nothing between the load and its use a round later needs its result.
   u64 todo = __ballot(valid && cnt > kFlatMax);
-  while (todo) {
-    const int src = (int)__builtin_ctzll(todo);
-    todo &= todo - 1ull;
-    const u32 count = (u32)__builtin_amdgcn_readlane((int)cnt, src);
-    const u64 lboff = ((u64)(u32)__builtin_amdgcn_readlane((int)(boff >> 32), src) << 32) |
-                      (u32)__builtin_amdgcn_readlane((int)boff, src);
-    const u64 lvoff = ((u64)(u32)__builtin_amdgcn_readlane((int)(voff >> 32), src) << 32) |
-                      (u32)__builtin_amdgcn_readlane((int)voff, src);
-    u32 run = (u32)__builtin_amdgcn_readlane((int)prev, src);
-    const u8* in = bytes + lboff;
-    u32* out = values + lvoff;
-    const u64 keylen = ((u64)count + 3) >> 2;
-    const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
-    u64 doff = 0;
-    auto load_keys = [&](u32 wt) -> u32 {
-      const u64 koff = (u64)wt * kWtKeys + 4 * lane;
-      return koff < keylen ? ld_u32(in + koff) : 0u;  // may overrun the keys by < 4 B: data or padding
+  if (!todo) return;
+  auto of_lane = [&](u64 x, int l) -> u64 {
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(x >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)x, l);
+  };
+  auto load_keys = [&](const u8* kaddr, u32 klim) -> u32 {  // klim >= 1 keys from kaddr on
+    return ld_u32(kaddr + min(4u * (u32)lane, (klim - 1u) & ~3u));  // may overrun the keys by < 4 B: data or padding
+  };
+  int src = (int)__builtin_ctzll(todo);
+  todo &= todo - 1ull;
+  u32 count = (u32)__builtin_amdgcn_readlane((int)cnt, src);
+  const u8* in = bytes + of_lane(boff, src);
+  u32* out = values + of_lane(voff, src);
+  u32 run = (u32)__builtin_amdgcn_readlane((int)prev, src);
+  u32 keylen = (count + 3u) >> 2;  // count > kFlatMax: at least 65 keys
+  u32 wt = 0;
+  u64 doff = 0;
+  u32 w_raw = load_keys(in, keylen);
+  for (;;) {
+    const u32 w = w_raw;
+    const u32 keys_left = keylen - wt * (u32)kWtKeys;  // from this wave tile on
+    const bool last_tile = keys_left <= (u32)kWtKeys;
+    int nsrc = -1;
+    {
+      const u8* kaddr = in;  // nothing follows: a harmless re-read of this stream's first keys
+      u32 klim = keylen;
+      if (!last_tile) {
+        kaddr = in + (u64)(wt + 1u) * kWtKeys;
+        klim = keys_left - (u32)kWtKeys;
+      } else if (todo) {
+        nsrc = (int)__builtin_ctzll(todo);
+        kaddr = bytes + of_lane(boff, nsrc);
+        klim = ((u32)__builtin_amdgcn_readlane((int)cnt, nsrc) + 3u) >> 2;
+      }
+      w_raw = load_keys(kaddr, klim);
+    }
+    const u64 int0 = (u64)wt * kWtInts;
+    uint4 v[4];
+    auto integrate = [&](uint4 c) -> uint4 {  // differences -> values, `run` carried along
+      if (DELTA) {
+        c.y += c.x; c.z += c.y; c.w += c.z;
+        const u32 incl = wave_scan_incl(c.w, lane);
+        const u32 ex = incl - c.w + run;
+        run += wave_last(incl);
+        c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+      }
+      return c;
     };
-    u32 w_next = load_keys(0);
-    for (u32 wt = 0; wt < n_wt; ++wt) {
-      const u32 w = w_next;
-      if (wt + 1 < n_wt) w_next = load_keys(wt + 1);  // the next wave tile's keys travel meanwhile
-      const u64 int0 = (u64)wt * kWtInts;
-      uint4 v[4];
-      auto integrate = [&](uint4 c) -> uint4 {  // differences -> values, `run` carried along
-        if (DELTA) {
-          c.y += c.x; c.z += c.y; c.w += c.z;
-          const u32 incl = wave_scan_incl(c.w, lane);
-          const u32 ex = incl - c.w + run;
-          run += wave_last(incl);
-          c.x += ex; c.y += ex; c.z += ex; c.w += ex;
-        }
-        return c;
-      };
-      if (int0 + kWtInts <= count) {
-        // a whole wave tile (wave-uniform): the length is a constant, so every bounds check of the
-        // tile decoder and of the stores folds away
-        doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, (u32)kWtInts, in + keylen + doff, lane, S, v);
-        u32* o = out + int0;
+    if (int0 + kWtInts <= count) {
+      // a whole wave tile (wave-uniform): the length is a constant, so every bounds check of the
+      // tile decoder and of the stores folds away
+      doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, (u32)kWtInts, in + keylen + doff, lane, S, v);
+      u32* o = out + int0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st_stream16<(NT & kNtStores) != 0>(o + 4u * (u32)(j * 64 + lane), integrate(v[j]));
-      } else {
-        const u32 nints = (u32)((u64)count - int0);
-        doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, nints, in + keylen + doff, lane, S, v);
+      for (int j = 0; j < 4; ++j) st_stream16<(NT & kNtStores) != 0>(o + 4u * (u32)(j * 64 + lane), integrate(v[j]));
+    } else {
+      const u32 nints = (u32)((u64)count - int0);
+      doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, nints, in + keylen + doff, lane, S, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (256u * j >= nints) break;  // wave-uniform: the stream's last wave tile ends before this quarter
-          store_group<(NT & kNtStores) != 0>(out, int0 + 4u * (j * 64 + lane), count, integrate(v[j]));
-        }
+      for (int j = 0; j < 4; ++j) {
+        if (256u * j >= nints) break;  // wave-uniform: the stream's last wave tile ends before this quarter
+        store_group<(NT & kNtStores) != 0>(out, int0 + 4u * (j * 64 + lane), count, integrate(v[j]));
       }
     }
-    if (sizes && lane == 0) sizes[s0 + src] = keylen + doff;
+    if (!last_tile) {
+      ++wt;
+      continue;
+    }
+    if (sizes && lane == 0) sizes[s0 + src] = (u64)keylen + doff;
+    if (nsrc < 0) break;
+    src = nsrc;
+    todo &= todo - 1ull;
+    count = (u32)__builtin_amdgcn_readlane((int)cnt, src);
+    in = bytes + of_lane(boff, src);
+    out = values + of_lane(voff, src);
+    run = (u32)__builtin_amdgcn_readlane((int)prev, src);
+    keylen = (count + 3u) >> 2;
+    wt = 0;
+    doff = 0;
   }
 }
 
