@@ -358,11 +358,21 @@ __device__ __forceinline__ void decode_batch2_body(
     u32 n_short, my_first;
     const u32 n_slots = flat_setup(is_short, cnt, boff, voff, prev, sid, lane, ent, n_short, my_first);
     u32 carry_idx = 0xFFFFFFFFu, carry_doff = 0, carry_val = 0;  // wave-uniform: the stream cut by the last step's end
+    if (n_slots == 0) return;
+    // A step's slots and key bytes depend on the directory alone, so they are worked out and requested a
+    // step ahead (one unconditional byte load at one place; lanes without a slot read their borrowed
+    // stream's first key): a step then waits for its data bytes only, not for its keys and then its data.
+    auto key_address = [&](const FlatSlot& t) -> const u8* { return bytes + t.e.boff + (t.have ? t.gi : 0u); };
+    FlatSlot f_next = flat_slot(0, n_slots, n_short, my_first, lane, ent);
+    u32 key_next = *key_address(f_next);
     for (u32 base = 0; base < n_slots; base += 64) {
-      const FlatSlot f = flat_slot(base, n_slots, n_short, my_first, lane, ent);
+      const FlatSlot f = f_next;
+      const u32 key_raw = key_next;
+      f_next = flat_slot(base + 64, n_slots, n_short, my_first, lane, ent);  // past the end: no lane has a slot
+      key_next = *key_address(f_next);
       const u8* in = bytes + f.e.boff;
       const u32 keylen = (f.e.cnt + 3u) >> 2;
-      u32 key = f.have ? in[f.gi] : 0u;
+      u32 key = f.have ? key_raw : 0u;
       const u32 nv = f.have ? min(4u, f.e.cnt - 4u * f.gi) : 0u;
       key &= nv >= 4u ? 0xFFu : ((1u << (2u * nv)) - 1u);
       const u32 L = group_len<V>(key, nv);
