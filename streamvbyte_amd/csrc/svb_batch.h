@@ -417,7 +417,7 @@ __device__ __forceinline__ void decode_batch2_body(
   const u8* in = bytes + of_lane(boff, src);
   u32* out = values + of_lane(voff, src);
   u32 run = (u32)__builtin_amdgcn_readlane((int)prev, src);
-  u32 keylen = (count + 3u) >> 2;  // count > kFlatMax: at least 65 keys
+  u32 keylen = (u32)(((u64)count + 3) >> 2);  // count > kFlatMax: at least 65 keys
   u32 wt = 0;
   u64 doff = 0;
   u32 w_raw = load_keys(in, keylen);
@@ -435,7 +435,7 @@ __device__ __forceinline__ void decode_batch2_body(
       } else if (todo) {
         nsrc = (int)__builtin_ctzll(todo);
         kaddr = bytes + of_lane(boff, nsrc);
-        klim = ((u32)__builtin_amdgcn_readlane((int)cnt, nsrc) + 3u) >> 2;
+        klim = (u32)(((u64)(u32)__builtin_amdgcn_readlane((int)cnt, nsrc) + 3) >> 2);
       }
       w_raw = load_keys(kaddr, klim);
     }
@@ -479,7 +479,7 @@ __device__ __forceinline__ void decode_batch2_body(
     in = bytes + of_lane(boff, src);
     out = values + of_lane(voff, src);
     run = (u32)__builtin_amdgcn_readlane((int)prev, src);
-    keylen = (count + 3u) >> 2;
+    keylen = (u32)(((u64)count + 3) >> 2);
     wt = 0;
     doff = 0;
   }
