@@ -619,14 +619,21 @@ __device__ __forceinline__ void encode_batch2_body(
       } else {
         const u32 nints = (u32)((u64)count - int0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = load_group<(NT & kNtLoads) != 0>(in, int0 + 4u * (j * 64 + lane), count);
+        for (int j = 0; j < 4; ++j) {
+          x[j] = make_uint4(0, 0, 0, 0);
+          if (256u * j < nints)  // wave-uniform: quarters past the stream's end load and classify nothing
+            x[j] = load_group<(NT & kNtLoads) != 0>(in, int0 + 4u * (j * 64 + lane), count);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          uint4 c = differences(x[j]);
-          const u64 first = int0 + 4u * (j * 64 + lane);
-          if (DELTA || ZZ) zero_absent(c, first, count);
-          x[j] = c;
-          g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
+          g[j] = 0u;  // no key bits, no bytes
+          if (256u * j < nints) {
+            uint4 c = differences(x[j]);
+            const u64 first = int0 + 4u * (j * 64 + lane);
+            if (DELTA || ZZ) zero_absent(c, first, count);
+            x[j] = c;
+            g[j] = classify_group<V, false>(c, first < count ? (u32)min((u64)4, (u64)count - first) : 0u);
+          }
         }
         doff += encode_wavetile<V, false, (NT & kNtStores) != 0>(x, g, nints, lane, S, out + keylen + doff, out + (int0 >> 2));
       }
