@@ -21,6 +21,7 @@
 #include "svb_decode.h"
 #include "svb_delta.h"
 #include "svb_encode.h"
+#include "svb_encode_stream.h"
 #include "svb_misc.h"
 #include "svb_batch.h"
 #include "svb_lists.h"
@@ -395,13 +396,42 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, 0u, (u64*)nullptr);
 }
+// The streaming encoder: a short-lived workgroup per tile of NW wave tiles (k_encode_stream), the ragged
+// last tile by k_encode<.., FULL = false> of the same tile size on the same look-back words.
+template <int V, bool D, bool Z, bool QUANT, int NW, int kC, int QW = 1>
+void launch_encode_stream(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
+                          uint64_t* d_written, hipStream_t st, size_t ws_bytes = 0) {
+  const WsLayout L = ws_layout(count);
+  constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
+  const unsigned full_tiles = (unsigned)(count / kTileInts);
+  const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
+  WsHeader* h = ws_hdr(ws);
+  const Lb4Words status{ws_at<u32>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+  u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2) ? ws_at<u64>(ws, L.total) : nullptr;
+  if (full_tiles && stamps && !QUANT && !D && !Z && V == V1234)  // diagnostic instantiation with the stamps compiled in
+    hipLaunchKernelGGL((k_encode_stream<V1234, false, false, false, NW, 3, kC, true, QW>), dim3(full_tiles), dim3(NW * 64), 0, st,
+                       d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug & ~16u, stamps);
+  else if (full_tiles)
+    SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
+                      hipLaunchKernelGGL((k_encode_stream<V, D, Z, QUANT, NW, NTV, kC, false, QW>), dim3(full_tiles), dim3(NW * 64), 0, st,
+                                         d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, (u64*)nullptr))
+  if (ragged)
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW, 0, kC>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
+                       d_out, prev, h, LbWords{reinterpret_cast<u64*>(status.tile), status.group}, d_written, 0u, (u64*)nullptr);
+}
 template <int V, bool D, bool Z>
 void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                    size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
   // Differential coding keeps the larger tiles of k_encode: posting-list gaps are mostly one byte, the
   // store phase is then short, and the pipelined kernel's twice as many tickets (one atomic on one word
   // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
-  if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  if (o.encode_pipeline == 3) launch_encode_stream<V, D, Z, false, 4, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
+  else if (o.encode_pipeline == 4) launch_encode_stream<V, D, Z, false, 8, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
+  else if (o.encode_pipeline == 5) launch_encode_stream<V, D, Z, false, 8, 1>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
+  else if (o.encode_pipeline == 6) launch_encode_stream<V, D, Z, false, 16, 1>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
+  else if (o.encode_pipeline == 7) launch_encode_stream<V, D, Z, false, 8, 1, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
+  else if (o.encode_pipeline == 8) launch_encode_stream<V, D, Z, false, 4, 1, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
+  else if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2 && o.encode_waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
@@ -468,7 +498,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
-      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 2; }},
+      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 8; }},
       {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
       {"nt_threshold_mib", &o_nt_threshold_mib, [](int v) { return v >= -1; }},
       {"nt_force", &o_nt_force, [](int v) { return v >= -1 && v <= 3; }},
