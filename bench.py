@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--lists", type=int, default=1 << 20, help="posting lists in the batched workload (whole job)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --stub)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="join a process group even with one rank, so that --gpus 1 runs the RCCL branch of the "
+                         "batched workload (all-gather of per-list sizes) like the multi-GPU job does")
     ap.add_argument("--stub", action="store_true",
                     help="rank plumbing only: every rank times a host memcpy instead of the GPU workload "
                          "(no GPU needed; used by the CPU test of the launcher)")
@@ -69,9 +72,22 @@ def launch_ranks(a):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # Poll: a rank that dies (a HIP failure on one GPU, say) would otherwise leave the others waiting in
+    # a barrier until the collective's own timeout, and its error buried; the first failure ends the job.
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code)
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
     return rc
 
 
@@ -323,11 +339,12 @@ def main():
     import streamvbyte_amd as svb
 
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         dist = dist_mod
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"

@@ -231,7 +231,9 @@ class DeviceCodec:
     torch's current stream of `device` and returns without synchronising.
     """
 
-    def __init__(self, max_count, device="cuda:0"):
+    def __init__(self, max_count, device="cuda:0", zero=True):
+        """zero=False skips the two fills of a fresh workspace and result block (every call clears what
+        it needs itself); for codecs made per call, whose memory comes from torch's caching allocator."""
         import torch
         self.torch = torch
         self.lib = load()
@@ -241,9 +243,10 @@ class DeviceCodec:
                 raise SvbError("no usable gfx950 device")
         self.max_count = int(max_count)
         self.ws_bytes = self.lib.svbgpu_workspace_bytes(self.max_count)
-        self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        make = torch.zeros if zero else torch.empty
+        self.ws = make(self.ws_bytes, dtype=torch.uint8, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
-        self.res = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self.res = make(8, dtype=torch.int64, device=self.device)
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream

@@ -8,6 +8,12 @@ LIB_PATH = os.environ.get("SVB_LIB_PATH") or os.path.join(HERE, "libstreamvbyte.
 u8p, u32p, i32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_int32, C.c_uint64))
 vp = C.c_void_p
 
+class MultiShard(C.Structure):
+    """svbmulti_shard_t of include/streamvbyte_multi.h."""
+    _fields_ = [("d_values", vp), ("d_value_off", vp), ("d_bytes", vp), ("d_byte_off", vp), ("d_counts", vp),
+                ("d_prev", vp), ("nstreams", C.c_uint32), ("d_sizes_all", vp), ("d_offsets_all", vp)]
+
+
 # name -> (restype, argtypes); mirrors include/*.h one to one
 SIGNATURES = {
     # include/streamvbyte.h
@@ -52,6 +58,16 @@ SIGNATURES = {
     "svbgpu_decode64": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_size_t, vp, vp]),
     "svbgpu_encode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbgpu_decode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    # include/streamvbyte_multi.h
+    "svbgpu_partition_streams": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
+    "svbmulti_create": (C.c_int, [vp, C.c_int, vp]),
+    "svbmulti_destroy": (None, [vp]),
+    "svbmulti_ndev": (C.c_int, [vp]),
+    "svbmulti_stream": (vp, [vp, C.c_int]),
+    "svbmulti_last_error": (C.c_char_p, []),
+    "svbmulti_encode_batch": (C.c_int, [vp, C.c_int, C.c_uint, vp]),
+    "svbmulti_decode_batch": (C.c_int, [vp, C.c_int, C.c_uint, vp]),
+    "svbmulti_synchronize": (C.c_int, [vp]),
     # include/streamvbyte_frame.h
     "svbgpu_validate_batch": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbframe_max_bytes": (C.c_size_t, [C.c_uint32]),

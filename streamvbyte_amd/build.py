@@ -37,7 +37,7 @@ def build(force=False, verbose=True):
            "-Wall", "-Wno-unused-function",
            "-Wl,-soname,libstreamvbyte.so.2",
            "-I", os.path.join(ROOT, "include"),
-           "-o", LIB, os.path.join(CSRC, "svb_api.hip")]
+           "-o", LIB, os.path.join(CSRC, "svb_api.hip"), "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,8 +1,9 @@
 // C ABI of libstreamvbyte.so.2: the device-pointer entry points of
 // include/streamvbyte_gpu.h and the reference-compatible host/device-pointer
 // functions of include/streamvbyte.h, streamvbytedelta.h, streamvbyte_zigzag.h.
-// Everything here launches HIP kernels; there is no CPU implementation of the
-// codec in this library.
+// Device pointers always run HIP kernels; host pointers do too from host_cpu_cutoff
+// values up, smaller host calls run the library's own host codec (svb_cpu.h) on the
+// calling thread.  The multi-device layer of include/streamvbyte_multi.h is at the end.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -11,22 +12,24 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/streamvbyte.h"
 #include "../../include/streamvbyte_gpu.h"
+#include "../../include/streamvbyte_multi.h"
 #include "../../include/streamvbyte_zigzag.h"
 #include "../../include/streamvbytedelta.h"
 #include "svb_cpu.h"
 #include "svb_decode.h"
 #include "svb_delta.h"
 #include "svb_encode.h"
-#include "svb_encode_stream.h"
 #include "svb_misc.h"
 #include "svb_batch.h"
 #include "svb_lists.h"
 #include "svb_intersect.h"
 #include "svb_wide.h"
+#include "svb_multi.h"
 
 using namespace svb;
 
@@ -396,42 +399,13 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, 0u, (u64*)nullptr);
 }
-// The streaming encoder: a short-lived workgroup per tile of NW wave tiles (k_encode_stream), the ragged
-// last tile by k_encode<.., FULL = false> of the same tile size on the same look-back words.
-template <int V, bool D, bool Z, bool QUANT, int NW, int kC, int QW = 1>
-void launch_encode_stream(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
-                          uint64_t* d_written, hipStream_t st, size_t ws_bytes = 0) {
-  const WsLayout L = ws_layout(count);
-  constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
-  const unsigned full_tiles = (unsigned)(count / kTileInts);
-  const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
-  WsHeader* h = ws_hdr(ws);
-  const Lb4Words status{ws_at<u32>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
-  u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2) ? ws_at<u64>(ws, L.total) : nullptr;
-  if (full_tiles && stamps && !QUANT && !D && !Z && V == V1234)  // diagnostic instantiation with the stamps compiled in
-    hipLaunchKernelGGL((k_encode_stream<V1234, false, false, false, NW, 3, kC, true, QW>), dim3(full_tiles), dim3(NW * 64), 0, st,
-                       d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug & ~16u, stamps);
-  else if (full_tiles)
-    SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
-                      hipLaunchKernelGGL((k_encode_stream<V, D, Z, QUANT, NW, NTV, kC, false, QW>), dim3(full_tiles), dim3(NW * 64), 0, st,
-                                         d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, (u64*)nullptr))
-  if (ragged)
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW, 0, kC>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
-                       d_out, prev, h, LbWords{reinterpret_cast<u64*>(status.tile), status.group}, d_written, 0u, (u64*)nullptr);
-}
 template <int V, bool D, bool Z>
 void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                    size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
   // Differential coding keeps the larger tiles of k_encode: posting-list gaps are mostly one byte, the
   // store phase is then short, and the pipelined kernel's twice as many tickets (one atomic on one word
   // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
-  if (o.encode_pipeline == 3) launch_encode_stream<V, D, Z, false, 4, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
-  else if (o.encode_pipeline == 4) launch_encode_stream<V, D, Z, false, 8, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
-  else if (o.encode_pipeline == 5) launch_encode_stream<V, D, Z, false, 8, 1>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
-  else if (o.encode_pipeline == 6) launch_encode_stream<V, D, Z, false, 16, 1>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
-  else if (o.encode_pipeline == 7) launch_encode_stream<V, D, Z, false, 8, 1, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
-  else if (o.encode_pipeline == 8) launch_encode_stream<V, D, Z, false, 4, 1, 2>(o, d_in, count, d_out, prev, ws, d_written, st, ws_bytes);
-  else if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2 && o.encode_waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
@@ -498,7 +472,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
-      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 8; }},
+      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 2; }},
       {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
       {"nt_threshold_mib", &o_nt_threshold_mib, [](int v) { return v >= -1; }},
       {"nt_force", &o_nt_force, [](int v) { return v >= -1 && v <= 3; }},
@@ -1403,3 +1377,226 @@ void zigzag_delta_decode(const uint32_t* in, int32_t* out, size_t N, int32_t pre
 
 #include "svb_frame.h"
 #include "svb_listframe.h"
+
+
+// =============================================================================
+// Batches over the devices of one node (include/streamvbyte_multi.h)
+// =============================================================================
+struct svbmulti {
+  int ndev = 0;
+  int dev[SVBMULTI_MAX_DEVICES];
+  hipStream_t stream[SVBMULTI_MAX_DEVICES];
+  ncclComm_t comm[SVBMULTI_MAX_DEVICES];
+  bool comms = false;
+  // per device: this shard's sizes padded to the longest shard, everybody's padded sizes, block sums
+  u64* pad[SVBMULTI_MAX_DEVICES];
+  u64* gathered[SVBMULTI_MAX_DEVICES];
+  u64* blk[SVBMULTI_MAX_DEVICES];
+  size_t cap_longest = 0, cap_blocks = 0;
+};
+
+namespace {
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+thread_local std::string g_multi_error;
+
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { (void)hipGetDevice(&prev); }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int multi_fail_hip(hipError_t e, const char* what) {
+  g_last_hip_error = e;
+  g_multi_error = std::string(what) + ": " + hipGetErrorString(e);
+  return SVBGPU_EHIP;
+}
+int multi_fail_rccl(ncclResult_t r, const char* what) {
+  g_multi_error = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+  return SVBMULTI_ERCCL;
+}
+#define MULTI_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return multi_fail_hip(e_, #expr); } while (0)
+#define MULTI_RCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return multi_fail_rccl(r_, #expr); } while (0)
+
+// Room for shards of up to `longest` streams and jobs of up to `blocks` blocks of 4096 streams.
+int multi_reserve(svbmulti* m, size_t longest, size_t blocks) {
+  if (longest <= m->cap_longest && blocks <= m->cap_blocks) return SVBGPU_OK;
+  const size_t nl = std::max(longest, m->cap_longest), nb = std::max(blocks, m->cap_blocks);
+  for (int i = 0; i < m->ndev; ++i) {
+    MULTI_HIP(hipSetDevice(m->dev[i]));
+    MULTI_HIP(hipStreamSynchronize(m->stream[i]));  // earlier calls may still read the old buffers
+    if (m->pad[i]) (void)hipFree(m->pad[i]);
+    if (m->gathered[i]) (void)hipFree(m->gathered[i]);
+    if (m->blk[i]) (void)hipFree(m->blk[i]);
+    m->pad[i] = m->gathered[i] = m->blk[i] = nullptr;
+    MULTI_HIP(hipMalloc(&m->pad[i], 8 * std::max<size_t>(nl, 1)));
+    MULTI_HIP(hipMalloc(&m->gathered[i], 8 * std::max<size_t>(nl, 1) * m->ndev));
+    MULTI_HIP(hipMalloc(&m->blk[i], 8 * std::max<size_t>(nb, 1)));
+  }
+  m->cap_longest = nl;
+  m->cap_blocks = nb;
+  return SVBGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* svbmulti_last_error(void) { return g_multi_error.c_str(); }
+
+int svbgpu_partition_streams(const uint32_t* counts, uint64_t nstreams, int world, uint64_t* cut) {
+  if (world < 1 || !cut || (nstreams && !counts)) return SVBGPU_EINVAL;
+  unsigned long long total = 0;
+  for (uint64_t s = 0; s < nstreams; ++s) total += counts[s];
+  // cut[r] = the first stream boundary at or past r / world of the values
+  cut[0] = 0;
+  uint64_t s = 0;
+  unsigned long long before = 0;  // values in streams 0 .. s-1
+  for (int r = 1; r < world; ++r) {
+    const unsigned long long target = (unsigned long long)((unsigned __int128)total * (unsigned)r / (unsigned)world);
+    while (s < nstreams && before < target) before += counts[s++];
+    cut[r] = s;
+  }
+  cut[world] = nstreams;
+  return SVBGPU_OK;
+}
+
+int svbmulti_create(const int* devices, int ndev, svbmulti_t** out) {
+  if (!out) return SVBGPU_EINVAL;
+  *out = nullptr;
+  if (!devices || ndev < 1 || ndev > SVBMULTI_MAX_DEVICES) return SVBGPU_EINVAL;
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have < 1) return SVBGPU_ENODEVICE;
+  for (int i = 0; i < ndev; ++i) {
+    if (devices[i] < 0 || devices[i] >= have) return SVBGPU_EINVAL;
+    for (int j = 0; j < i; ++j)
+      if (devices[j] == devices[i]) return SVBGPU_EINVAL;
+  }
+  DeviceGuard guard;
+  for (int i = 0; i < ndev; ++i) {
+    MULTI_HIP(hipSetDevice(devices[i]));
+    if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.load(g_multi_error)) return SVBMULTI_ERCCL;
+  }
+  svbmulti* m = new svbmulti();
+  m->ndev = ndev;
+  for (int i = 0; i < ndev; ++i) {
+    m->dev[i] = devices[i];
+    m->stream[i] = nullptr;
+    m->pad[i] = m->gathered[i] = m->blk[i] = nullptr;
+  }
+  auto fail = [&](int rc) { svbmulti_destroy(m); return rc; };
+  for (int i = 0; i < ndev; ++i) {
+    hipError_t e = hipSetDevice(m->dev[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream[i], hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(multi_fail_hip(e, "hipStreamCreateWithFlags"));
+  }
+  const ncclResult_t r = g_rccl.CommInitAll(m->comm, ndev, m->dev);
+  if (r != ncclSuccess) return fail(multi_fail_rccl(r, "ncclCommInitAll"));
+  m->comms = true;
+  *out = m;
+  return SVBGPU_OK;
+}
+
+void svbmulti_destroy(svbmulti_t* m) {
+  if (!m) return;
+  DeviceGuard guard;
+  for (int i = 0; i < m->ndev; ++i) {
+    if (hipSetDevice(m->dev[i]) != hipSuccess) continue;
+    if (m->stream[i]) (void)hipStreamSynchronize(m->stream[i]);
+    if (m->comms) (void)g_rccl.CommDestroy(m->comm[i]);
+    if (m->pad[i]) (void)hipFree(m->pad[i]);
+    if (m->gathered[i]) (void)hipFree(m->gathered[i]);
+    if (m->blk[i]) (void)hipFree(m->blk[i]);
+    if (m->stream[i]) (void)hipStreamDestroy(m->stream[i]);
+  }
+  delete m;
+}
+
+int svbmulti_ndev(const svbmulti_t* m) { return m ? m->ndev : 0; }
+void* svbmulti_stream(svbmulti_t* m, int i) { return m && i >= 0 && i < m->ndev ? m->stream[i] : nullptr; }
+
+int svbmulti_synchronize(svbmulti_t* m) {
+  if (!m) return SVBGPU_EINVAL;
+  DeviceGuard guard;
+  for (int i = 0; i < m->ndev; ++i) {
+    MULTI_HIP(hipSetDevice(m->dev[i]));
+    MULTI_HIP(hipStreamSynchronize(m->stream[i]));
+  }
+  return SVBGPU_OK;
+}
+
+int svbmulti_encode_batch(svbmulti_t* m, int variant, unsigned flags, const svbmulti_shard_t* shards) {
+  if (!m || !shards || bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  ShardStarts S{};
+  S.n = (u32)m->ndev;
+  size_t longest = 0;
+  for (int i = 0; i < m->ndev; ++i) {
+    if (!shards[i].d_sizes_all) return SVBGPU_EINVAL;
+    S.start[i + 1] = S.start[i] + shards[i].nstreams;
+    longest = std::max<size_t>(longest, shards[i].nstreams);
+  }
+  const u64 n_all = S.start[m->ndev];
+  if (n_all >= (1ull << 32)) return SVBGPU_EINVAL;
+  S.longest = (u32)std::max<size_t>(longest, 1);
+  const unsigned blocks = (unsigned)((n_all + 4095) / 4096);
+  DeviceGuard guard;
+  int rc = multi_reserve(m, longest, blocks);
+  if (rc) return rc;
+  // 1. every shard on its own device and stream; sizes land in the padded send buffer
+  for (int i = 0; i < m->ndev; ++i) {
+    const svbmulti_shard_t& h = shards[i];
+    MULTI_HIP(hipSetDevice(m->dev[i]));
+    if (h.nstreams < S.longest) {
+      rc = fill_u32(m->pad[i] + h.nstreams, 0u, 8 * (size_t)(S.longest - h.nstreams), m->stream[i]);
+      if (rc) return rc;
+    }
+    rc = svbgpu_encode_batch(variant, flags, h.d_values, h.d_value_off, h.d_bytes, h.d_byte_off, h.d_counts, h.d_prev,
+                             h.nstreams, m->pad[i], m->stream[i]);
+    if (rc) return rc;
+  }
+  // 2. the one exchange: 8 bytes per stream, every device receives every shard's sizes
+  MULTI_RCCL(g_rccl.GroupStart());
+  for (int i = 0; i < m->ndev; ++i) {
+    const ncclResult_t r = g_rccl.AllGather(m->pad[i], m->gathered[i], S.longest, ncclUint64, m->comm[i], m->stream[i]);
+    if (r != ncclSuccess) {
+      (void)g_rccl.GroupEnd();
+      return multi_fail_rccl(r, "ncclAllGather");
+    }
+  }
+  MULTI_RCCL(g_rccl.GroupEnd());
+  // 3. job order without the padding, and the byte directory, on every device
+  for (int i = 0; i < m->ndev && blocks; ++i) {
+    MULTI_HIP(hipSetDevice(m->dev[i]));
+    hipLaunchKernelGGL(k_multi_compact, dim3(blocks), dim3(1024), 0, m->stream[i], m->gathered[i], S, shards[i].d_sizes_all,
+                       m->blk[i]);
+    if (shards[i].d_offsets_all)
+      hipLaunchKernelGGL(k_multi_offsets, dim3(blocks), dim3(1024), 0, m->stream[i], shards[i].d_sizes_all, n_all, m->blk[i],
+                         shards[i].d_offsets_all);
+    MULTI_HIP(hipGetLastError());
+  }
+  for (int i = 0; i < m->ndev && !blocks; ++i)  // an empty job still has a total
+    if (shards[i].d_offsets_all) {
+      MULTI_HIP(hipSetDevice(m->dev[i]));
+      rc = fill_u32(shards[i].d_offsets_all, 0u, 8, m->stream[i]);
+      if (rc) return rc;
+    }
+  return SVBGPU_OK;
+}
+
+int svbmulti_decode_batch(svbmulti_t* m, int variant, unsigned flags, const svbmulti_shard_t* shards) {
+  if (!m || !shards || bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  DeviceGuard guard;
+  for (int i = 0; i < m->ndev; ++i) {
+    const svbmulti_shard_t& h = shards[i];
+    MULTI_HIP(hipSetDevice(m->dev[i]));
+    const int rc = svbgpu_decode_batch(variant, flags, h.d_bytes, h.d_byte_off, const_cast<uint32_t*>(h.d_values), h.d_value_off,
+                                       h.d_counts, h.d_prev, h.nstreams, nullptr, m->stream[i]);
+    if (rc) return rc;
+  }
+  return SVBGPU_OK;
+}
+
+}  // extern "C"

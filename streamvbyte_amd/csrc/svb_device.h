@@ -295,7 +295,7 @@ __host__ __device__ constexpr WsLayout ws_layout(u32 count) {
   L.n_tiles = (L.n_wt + kLbWt - 1) / kLbWt;
   size_t o = sizeof(WsHeader);
   // the look-back words follow the header so one memset clears both
-  L.off_status = o;    o += align256(8 * (L.n_wt / kWaves + 2 + 8 * 32));  // room for the smallest tile size, dealt over 8 arrays
+  L.off_status = o;    o += align256(8 * (L.n_wt / kWaves + 2));  // room for the smallest tile size
   L.off_lb_group = o;  o += align256(8 * (L.n_wt / kWaves / 16 + 2));  // group words of the two-level look-back
   // offset directory: the key block is cut into at most kMegas equal runs of whole super tiles
   const u64 spm = (L.n_super + kMegas - 1) / kMegas;  // super tiles per mega tile (0 for an empty stream)

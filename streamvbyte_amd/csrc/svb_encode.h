@@ -328,9 +328,7 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // QUANT: the input holds float32; every value becomes (int32)rintf(x * scale) first
 // (scale travels as the bits of `prev`, which only DELTA uses otherwise) -- the
 // quantise step of gradient compression fused into the encoder's load.
-// LB4 > 0: the tile words are the 4-byte words of the short-tile look-back (Lb4Words: lb.tile points at
-// u32 words), read LB4 chunks per lane -- the ragged last tile behind k_encode_stream.
-template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves, int NT = 0, int LB4 = 0>
+template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves, int NT = 0>
 __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
@@ -442,11 +440,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
     for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[w];
     u64 excl = 0;
     u32 rounds = 0;
-    if (LB4 > 0) {
-      const Lb4Words l4{reinterpret_cast<u32*>(lb.tile), lb.group};
-      Lb4Polls<(LB4 > 0 ? LB4 : 1)> polls = lb4_begin<(LB4 > 0 ? LB4 : 1)>(l4, tile, tile_tot, lane);
-      excl = lb4_resolve<(LB4 > 0 ? LB4 : 1)>(l4, tile, tile_tot, lane, polls, &hdr->error, &rounds);
-    } else if (!(dbg & 1u)) {
+    if (!(dbg & 1u)) {
       excl = lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error, &rounds);
     } else {
       excl = (u64)tile * (kTileInts * 5 / 2);  // timing experiment: no look-back, plausible (wrong) offsets

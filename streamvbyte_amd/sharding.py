@@ -29,20 +29,24 @@ def partition_streams(counts, world):
 
 def all_gather_sizes(dist, local_sizes, cut):
     """All-gather per-stream sizes (torch int64 tensor of this rank's streams).
-    Shards may differ in length, so each rank pads to the longest shard.
-    Returns (sizes_all, offsets_all): global per-stream sizes and their
-    exclusive prefix sum (the byte directory), as torch tensors on the same
-    device as `local_sizes`."""
+    Shards may differ in length, so each rank pads to the longest shard; one collective into one
+    flat tensor (`all_gather_into_tensor`: no list of per-rank buffers, no `cat` when the shards are
+    equally long).  Returns (sizes_all, offsets_all): global per-stream sizes and their exclusive
+    prefix sum (the byte directory), as torch tensors on the same device as `local_sizes`."""
     import torch
     world = dist.get_world_size()
     lens = [int(cut[r + 1] - cut[r]) for r in range(world)]
     longest = max(lens) if lens else 0
-    pad = torch.zeros(longest, dtype=torch.int64, device=local_sizes.device)
-    pad[: local_sizes.numel()] = local_sizes
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    sizes_all = torch.cat([bufs[r][: lens[r]] for r in range(world)]) if world else pad
-    offsets = torch.zeros_like(sizes_all)
-    if sizes_all.numel() > 1:
-        offsets[1:] = torch.cumsum(sizes_all[:-1], 0)
+    if local_sizes.numel() == longest:
+        pad = local_sizes.contiguous()
+    else:
+        pad = torch.zeros(longest, dtype=torch.int64, device=local_sizes.device)
+        pad[: local_sizes.numel()] = local_sizes
+    flat = torch.empty(world * longest, dtype=torch.int64, device=local_sizes.device)
+    dist.all_gather_into_tensor(flat, pad)
+    if all(n == longest for n in lens):
+        sizes_all = flat
+    else:
+        sizes_all = torch.cat([flat[r * longest: r * longest + lens[r]] for r in range(world)])
+    offsets = torch.cumsum(sizes_all, 0) - sizes_all
     return sizes_all, offsets

@@ -16,26 +16,23 @@ one-element int64 tensors so that nothing synchronises.  The operators only move
 pointers: all arithmetic is the HIP library's, and without it (or without a gfx950
 device) they raise.
 """
-import threading
-
 import torch
 
 from . import DeviceCodec, streamvbyte_max_compressedbytes
 
-_codecs = {}
-_lock = threading.Lock()
-
 
 def _codec(device, count):
-    """One workspace per (thread, device), grown to the largest count seen: calls of one thread are
-    ordered on its current stream, which is what sharing a workspace needs."""
-    key = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
-    with _lock:
-        c = _codecs.get(key)
-        if c is None or c.max_count < count:
-            c = DeviceCodec(max(count, 1 << 20), torch.device("cuda", key[1]))
-            _codecs[key] = c
-    return c
+    """A workspace and result words of this call's own, allocated on torch's current stream.
+
+    The library's workspace (offset directory, look-back words, size words) may be used by one call at a
+    time.  A workspace kept per thread or per device would be shared by calls that one thread issues on
+    different torch streams without synchronising, and they would overwrite each other's directory.
+    torch's caching allocator is stream-aware: a block allocated while stream s is current is handed
+    out again on another stream only after the work s had queued when it was freed has finished, so a
+    fresh `torch.empty` per call is exactly the ownership the library asks for, at the cost of a cache
+    lookup (no hipMalloc in steady state).  Nothing needs zeroing: every call clears what it reads."""
+    return DeviceCodec(max(count, 1), torch.device("cuda", device.index if device.index is not None
+                                                   else torch.cuda.current_device()), zero=False)
 
 
 def _check_values(values):
@@ -49,7 +46,7 @@ def encode(values: torch.Tensor, variant: int, flags: int, prev: int) -> tuple[t
     c = _codec(values.device, values.numel())
     out = torch.empty(streamvbyte_max_compressedbytes(values.numel()), dtype=torch.uint8, device=values.device)
     _, size = c.encode(values, out=out, variant=variant, flags=flags, prev=prev)
-    return out, size.clone()
+    return out, size
 
 
 @encode.register_fake
@@ -76,7 +73,7 @@ def _(stream, count, variant, flags, prev):
 @torch.library.custom_op("svb::compressedbytes", mutates_args=(), device_types="cuda")
 def compressedbytes(values: torch.Tensor, variant: int, flags: int, prev: int) -> torch.Tensor:
     _check_values(values)
-    return _codec(values.device, values.numel()).compressedbytes(values, variant=variant, flags=flags, prev=prev).clone()
+    return _codec(values.device, values.numel()).compressedbytes(values, variant=variant, flags=flags, prev=prev)
 
 
 @compressedbytes.register_fake
@@ -87,7 +84,7 @@ def _(values, variant, flags, prev):
 @torch.library.custom_op("svb::validate", mutates_args=(), device_types="cuda")
 def validate(stream: torch.Tensor, in_length: int, count: int, variant: int) -> torch.Tensor:
     c = _codec(stream.device, count)
-    return (c.validate(stream, in_length, count, variant=variant) & 1).clone()
+    return c.validate(stream, in_length, count, variant=variant) & 1
 
 
 @validate.register_fake

@@ -65,3 +65,39 @@ def test_all_gather_sizes_gloo(world):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     assert all(out[r] for r in range(world)) and len(out) == world
+
+
+def test_c_partition_matches_the_python_one():
+    """svbgpu_partition_streams (include/streamvbyte_multi.h) is the same cut as partition_streams."""
+    import ctypes as C
+    import streamvbyte_amd as svb
+    lib = svb.load()
+    rng = np.random.default_rng(5)
+    cases = [np.floor(np.exp(rng.uniform(0, np.log(4096), size=s))).astype(np.uint32) for s in (0, 1, 7, 5000)]
+    cases.append(np.zeros(9, dtype=np.uint32))
+    cases.append(np.full(11, 2**32 - 1, dtype=np.uint32))  # totals beyond 32 bits
+    for counts in cases:
+        for world in (1, 2, 3, 8, 64):
+            cut = np.zeros(world + 1, dtype=np.uint64)
+            rc = lib.svbgpu_partition_streams(counts.ctypes.data_as(C.c_void_p), counts.size, world,
+                                              cut.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            assert np.array_equal(cut.astype(np.int64), partition_streams(counts, world)), (counts.size, world)
+    assert lib.svbgpu_partition_streams(None, 0, 0, None) == -1
+
+
+def test_multi_device_context_needs_devices():
+    """Without a GPU svbmulti_create fails with an error code (no RCCL is loaded, nothing aborts)."""
+    import ctypes as C
+    import torch
+    import streamvbyte_amd as svb
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu tests")
+    lib = svb.load()
+    handle = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert lib.svbmulti_create(dev, 1, C.byref(handle)) in (-2, -4)
+    assert not handle.value
+    assert lib.svbmulti_create(dev, 0, C.byref(handle)) == -1
+    assert lib.svbmulti_ndev(None) == 0
+    lib.svbmulti_destroy(None)

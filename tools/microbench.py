@@ -83,40 +83,6 @@ if want("encode"):
     ops["encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_early"] = (opt_with(b"encode_ticket_early", 1, -1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(2, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
-if want("stream"):
-    ref_out = torch.empty_like(enc_out)
-    _, rsz = codec.encode(values, out=ref_out)
-    for mode in (4, 6, 7, 8):
-        codec.lib.svbgpu_set_option(b"encode_pipeline", mode)
-        _, tsz = codec.encode(values, out=enc_out)
-        codec.check()
-        ok = int(tsz.item()) == int(rsz.item()) and bool(torch.equal(enc_out[:size], ref_out[:size]))
-        print(f"stream mode {mode}: bytes equal to the pipelined encoder's: {ok}", flush=True)
-        codec.lib.svbgpu_set_option(b"encode_pipeline", 1)
-    del ref_out
-    ops["encode"] = (lambda: codec.encode(values, out=enc_out), (4.25 + dbar) * n)
-    for mode in (4, 6, 7, 8):
-        ops[f"encode_stream{mode}"] = (opt_with(b"encode_pipeline", mode, 1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
-        ops[f"encode_stream{mode}_nolb"] = (opt_with(b"encode_pipeline", mode, 1, dbg_with(1, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
-    ops["delta_encode_mixed"] = (lambda: codec.encode(values, out=enc_out, flags=svb.DELTA), (4.25 + dbar) * n)
-    for mode in (2, 4, 7, 8):
-        ops[f"delta_encode_mixed_m{mode}"] = (opt_with(b"encode_pipeline", mode, 1, lambda: codec.encode(values, out=enc_out, flags=svb.DELTA)), (4.25 + dbar) * n)
-    g = torch.Generator(device=dev); g.manual_seed(7)
-    post = torch.cumsum(torch.randint(0, 32, (n,), generator=g, device=dev, dtype=torch.int64), 0)
-    post = torch.where(post >= (1 << 31), post - (1 << 32), post).to(torch.int32)
-    _, z3 = codec.encode(post, out=enc_out, flags=svb.DELTA)
-    d3 = (int(z3.item()) - keylen) / n
-    ops["delta_encode_dense"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
-    for mode in (4, 7, 8):
-        ops[f"delta_encode_dense_m{mode}"] = (opt_with(b"encode_pipeline", mode, 1, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
-    n4 = min(n, 1 << 26)
-    g = torch.Generator(device=dev); g.manual_seed(9)
-    gr = torch.round(torch.randn(n4, generator=g, device=dev) * 0.8).to(torch.int32)
-    _, z4 = codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)
-    d4 = (int(z4.item()) - (n4 + 3) // 4) / n4
-    ops["zz0124_encode"] = (lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
-    for mode in (4, 6, 7, 8):
-        ops[f"zz0124_encode_m{mode}"] = (opt_with(b"encode_pipeline", mode, 1, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
 if want("encode_qw"):
     for qw in (1, 2, 4):
         ops[f"encode_qw{qw}"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(qw, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
