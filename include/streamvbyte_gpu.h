@@ -56,6 +56,11 @@ const char *svbgpu_strerror(int code);
 
 /* 1 when the current HIP device is a gfx950 the library can run on. */
 int svbgpu_device_ok(void);
+/* 1 if this build of the library has the named diagnostic feature compiled in, else 0.
+ * "lookback_stress": the build in which svbgpu_set_option("debug_ablate", 64) delays a random quarter
+ * of the look-back's publications by tens of microseconds (libstreamvbyte_stress.so.2; results stay
+ * exact, speed does not). */
+int svbgpu_build_has(const char *feature);
 
 /* Tuning knobs.  Each is an atomic word; every API call reads all of them once
  * on entry and works from that snapshot, so a change never reaches a call that
@@ -106,7 +111,7 @@ int svbgpu_device_ok(void);
  *                               with the wave tiles strided over it (slower:
  *                               kept for comparison)
  *   "batch_chunk" = k           batched calls: -1 (default) every wavefront takes
- *                               k = 32 (decode) or 8 (encode) consecutive streams,
+ *                               k = 16 (decode) or 8 (encode) consecutive streams,
  *                               short ones packed a group of four values per lane
  *                               across stream borders, long ones a wave tile at a
  *                               time; k in 1..64 sets the number; 0: the older
@@ -177,12 +182,20 @@ int svbgpu_decode_run(int variant, unsigned flags, const uint8_t *d_in, uint32_t
  *     (same stream, or events between streams); two that overlap race on the
  *     directory and give wrong values.  Different GPUs never interfere.
  *   - svbgpu_check_status does not apply (there is no workspace pointer to
- *     give it); the look-back's bounded spin still guarantees termination.
+ *     give it); the look-back's bounded spin still guarantees termination, and
+ *     svbgpu_static_status reports whether one gave up.
  *   - The first call on a device looks the array's address up
  *     (hipGetSymbolAddress); make that call before starting a capture. */
 #define SVBGPU_STATIC_MAX_COUNT (1u << 28)
 int svbgpu_decode_static(int variant, unsigned flags, const uint8_t *d_in, uint32_t *d_out,
                          uint32_t count, uint32_t prev, uint64_t *d_consumed, void *stream);
+/* The error word of this GPU's static scratch, for callers of svbgpu_decode_static (no counterpart
+ * in the reference; like that call it allocates nothing and only enqueues a kernel): *d_error
+ * (a device word) becomes 0, or non-zero if a bounded spin of the last svbgpu_decode_static call
+ * queued before it on `stream` gave up (its output is then wrong: decode again with
+ * svbgpu_set_option("delta_decode_lookback", 0), which waits on nothing).  Read the word after
+ * synchronising the stream. */
+int svbgpu_static_status(uint32_t *d_error, void *stream);
 
 /* Device-pointer form of streamvbyte_encode / _encode_0124 /
  * streamvbyte_delta_encode (reference include/streamvbyte.h:23,27,
@@ -284,9 +297,11 @@ int svbgpu_decode64(const uint8_t *d_in, uint64_t *d_out, uint32_t count, void *
  * streamvbyte_max_compressedbytes(d_counts[s]) bytes for stream s and
  * d_sizes[s] receives the bytes written; for decode d_sizes[s] (optional)
  * receives the bytes consumed.
- * A stream is handled by one 16-lane row (up to 256 values) or one wavefront,
- * which suits streams of up to some 10^5 values; give longer ones to the
- * single-stream calls above, which spread one stream over the whole device.
+ * A wavefront takes a run of consecutive streams: those of up to 256 values
+ * are packed a group of four values per lane across stream borders, longer
+ * ones go a wave tile (1024 values) at a time.  That suits streams of up to
+ * some 10^5 values; give longer ones to the single-stream calls above, which
+ * spread one stream over the whole device.
  */
 int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t *d_values,
                         const uint64_t *d_value_off, uint8_t *d_bytes, const uint64_t *d_byte_off,

@@ -36,6 +36,7 @@ SIGNATURES = {
     # include/streamvbyte_gpu.h
     "svbgpu_strerror": (C.c_char_p, [C.c_int]),
     "svbgpu_device_ok": (C.c_int, []),
+    "svbgpu_build_has": (C.c_int, [C.c_char_p]),
     "svbgpu_workspace_bytes": (C.c_size_t, [C.c_uint32]),
     "svbgpu_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "svbgpu_check_status": (C.c_int, [vp, vp]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "svbgpu_decode_plan": (C.c_int, [C.c_int, vp, C.c_uint32, vp, C.c_size_t, vp]),
     "svbgpu_decode_run": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]),
     "svbgpu_decode_static": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, vp]),
+    "svbgpu_static_status": (C.c_int, [vp, vp]),
     "svbgpu_encode": (C.c_int, [C.c_int, C.c_uint, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_size_t, vp, vp]),
     "svbgpu_quantize_encode": (C.c_int, [C.c_int, vp, C.c_uint32, C.c_float, vp, vp, C.c_size_t, vp, vp]),
     "svbgpu_decode_dequantize": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_float, C.c_int, vp, C.c_size_t, vp, vp]),

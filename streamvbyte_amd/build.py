@@ -14,6 +14,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstreamvbyte.so.2")
 LINK = os.path.join(HERE, "libstreamvbyte.so")
+# the same library with the look-back's stress hooks compiled in (csrc/svb_lookback.h: lb_stress_delay);
+# loaded only by tests/test_gpu_lookback_stress.py, through SVB_LIB_PATH
+STRESS_LIB = os.path.join(HERE, "libstreamvbyte_stress.so.2")
 
 
 def sources():
@@ -22,28 +25,39 @@ def sources():
     return out
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force=False, verbose=True):
-    if not force and not stale():
-        return LIB
+def _compile(out, extra, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
+           "-Wall", "-Wno-unused-function", *extra,
            "-Wl,-soname,libstreamvbyte.so.2",
            "-I", os.path.join(ROOT, "include"),
-           "-o", LIB, os.path.join(CSRC, "svb_api.hip"), "-ldl"]
+           "-o", out, os.path.join(CSRC, "svb_api.hip"), "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    if os.path.lexists(LINK):
-        os.remove(LINK)
-    os.symlink(os.path.basename(LIB), LINK)
+    return subprocess.Popen(cmd)
+
+
+def build(force=False, verbose=True):
+    """Both libraries, compiled side by side (two hipcc processes)."""
+    jobs = []
+    if force or stale(LIB):
+        jobs.append(_compile(LIB, [], verbose))
+    if force or stale(STRESS_LIB):
+        jobs.append(_compile(STRESS_LIB, ["-DSVB_LB_STRESS"], verbose))
+    for j in jobs:
+        if j.wait() != 0:
+            raise subprocess.CalledProcessError(j.returncode, j.args)
+    if jobs:
+        if os.path.lexists(LINK):
+            os.remove(LINK)
+        os.symlink(os.path.basename(LIB), LINK)
     return LIB
 
 

@@ -206,9 +206,18 @@ int check_ws(uint32_t count, void* ws, size_t ws_bytes) {
 }
 
 // header + look-back words start every call at zero
+// Stress build only: "debug_ablate" bit 64 arms lb_stress_delay for the kernels that follow.
+int arm_lookback_stress(void* ws, hipStream_t st) {
+#ifdef SVB_LB_STRESS
+  if (options().debug & 64u) return fill_u32(reinterpret_cast<u32*>(ws) + kLbStressWord, 1u, 4, st);
+#endif
+  (void)ws; (void)st;
+  return SVBGPU_OK;
+}
 int clear_lookback(uint32_t count, void* ws, hipStream_t st) {
   const WsLayout L = ws_layout(count);
-  return fill_u32(ws, 0u, L.off_mega_sum, st);
+  const int rc = fill_u32(ws, 0u, L.off_mega_sum, st);
+  return rc ? rc : arm_lookback_stress(ws, st);
 }
 
 // ---- offset directory -------------------------------------------------------
@@ -228,7 +237,7 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   else
     hipLaunchKernelGGL(k_key_sums<V0124>, dim3(L.n_mega), dim3(1024), 0, st, d_in, count, wt_rel, mega_sum, spm, clr, clr_n);
   HIP_TRY(hipGetLastError());
-  return SVBGPU_OK;
+  return clear_lb ? arm_lookback_stress(ws, st) : SVBGPU_OK;
 }
 inline Dir ws_dir(void* ws, const WsLayout& L) {
   return Dir{ws_at<u32>(ws, L.off_mega_sum), ws_at<u32>(ws, L.off_wt_rel), L.wt_per_mega};
@@ -405,7 +414,7 @@ void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8
   // Differential coding keeps the larger tiles of k_encode: posting-list gaps are mostly one byte, the
   // store phase is then short, and the pipelined kernel's twice as many tickets (one atomic on one word
   // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
-  if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~16u)) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~(16u | 64u))) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2 && o.encode_waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
@@ -457,6 +466,14 @@ const char* svbgpu_strerror(int code) {
 }
 
 int svbgpu_device_ok(void) { return dev_info().ok ? 1 : 0; }
+
+int svbgpu_build_has(const char* feature) {
+  if (!feature) return 0;
+#ifdef SVB_LB_STRESS
+  if (!std::strcmp(feature, "lookback_stress")) return 1;
+#endif
+  return 0;
+}
 
 int svbgpu_set_option(const char* name, int value) {
   if (!name) return SVBGPU_EINVAL;
@@ -602,6 +619,17 @@ int svbgpu_decode_static(int variant, unsigned flags, const uint8_t* d_in, uint3
   rc = build_directory(variant, d_in, count, ws, S(stream), fold_clear);
   if (rc) return rc;
   return run_decode(o, variant, flags, d_in, d_out, count, prev, ws, d_consumed, S(stream), 0, fold_clear);
+}
+
+int svbgpu_static_status(uint32_t* d_error, void* stream) {
+  if (!d_error) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  void* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(64), 0, S(stream), &ws_hdr(ws)->error, d_error);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
 }
 
 int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t count, uint8_t* d_out,

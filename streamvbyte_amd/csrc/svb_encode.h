@@ -623,7 +623,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
     if (wave == 0) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[buf][w];
-      lb2_publish(lb, tile, tile_tot, lane);
+      lb2_publish(lb, tile, tile_tot, lane, &hdr->error);
       if (stamps && lane == 0) stamps[5 * (u64)tile + 1] = __builtin_amdgcn_s_memrealtime();
     }
     return tile_tot;

@@ -49,7 +49,27 @@ struct LbWords {
 //   lb2_publish   the tile's aggregate becomes visible to later tiles
 //   lb2_resolve   poll until the exclusive prefix of the tile is known
 // lb2_exclusive_prefix is one after the other.
-__device__ __forceinline__ void lb2_publish(const LbWords& L, u32 tile, u64 my_agg, int lane) {
+// Stress build of the look-back (-DSVB_LB_STRESS, libstreamvbyte_stress.so.2; results stay exact).
+// With svbgpu_set_option("debug_ablate", 64) the first word of the workspace header's second 128-byte
+// line -- err[32], zero otherwise -- makes a pseudo-random quarter of the tiles sleep for tens of
+// microseconds right before they publish (salt 0), before a leader publishes its group's aggregate (1)
+// and before it publishes the group's prefix (2), so that words arrive late and out of order however
+// evenly the hardware happens to run.  The protocol must give the same bytes under any such timing; the
+// parity tests run once against that build.  Not in the product build: even as a never-taken branch
+// on a cached scalar load the hook cost the encoder 2.5-3 % (same box, alternating builds), and placed
+// in the ticket's cache line, which the whole device hammers with atomics, it tripled its time.
+constexpr int kLbStressWord = 32;
+__device__ __forceinline__ void lb_stress_delay(const u32* err, u32 tile, u32 salt) {
+#ifdef SVB_LB_STRESS
+  if (!err || !err[kLbStressWord]) return;  // wave-uniform
+  const u32 h = (tile * 2654435761u + salt * 40503u) >> 13;
+  if (h & 3u) return;
+  const int naps = 2 + (int)((h >> 2) & 7u);  // about 8 .. 35 us
+  for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+}
+__device__ __forceinline__ void lb2_publish(const LbWords& L, u32 tile, u64 my_agg, int lane, const u32* err = nullptr) {
+  lb_stress_delay(err, tile, 0);
   if (lane == 0) __hip_atomic_store(L.tile + tile, kLbAgg | my_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // What the first poll round of a look-back read (lb2_begin): words not yet
@@ -112,6 +132,7 @@ __device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_ag
       // the group is complete: let later groups count it
       agg_out = true;
       const u64 gagg = wave_sum64(lane < 15 ? (tw[0] & kLbVal) : 0ull) + my_agg;
+      lb_stress_delay(err, tile, 1);
       if (lane == 0)
         __hip_atomic_store(L.group + k, (k ? kLbAgg : kLbPfx) | gagg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -155,6 +176,7 @@ __device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_ag
     }
   }
   const u64 prefix = wave_sum64(mine);
+  if (leader && k) lb_stress_delay(err, tile, 2);
   if (leader && k && lane == 0)
     __hip_atomic_store(L.group + k, kLbPfx | (prefix + my_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (rounds_out) *rounds_out = rounds | (tile_round << 8) | (group_round << 16);
@@ -163,7 +185,7 @@ __device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_ag
 template <int kT = 2>
 __device__ __forceinline__ u64 lb2_exclusive_prefix(const LbWords& L, u32 tile, u64 my_agg, int lane,
                                                     u32* err, u32* rounds_out = nullptr) {
-  lb2_publish(L, tile, my_agg, lane);
+  lb2_publish(L, tile, my_agg, lane, err);
   return lb2_resolve<kT>(L, tile, my_agg, lane, err, rounds_out);
 }
 

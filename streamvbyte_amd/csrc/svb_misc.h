@@ -12,6 +12,11 @@ __global__ void k_fill_u32(u32* __restrict__ p, u32 value, u64 n) {
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = value;
 }
 
+// *dst = *src (one word, one thread).
+__global__ void k_copy_u32(const u32* __restrict__ src, u32* __restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+}
+
 // Sticky error: OR the error word of a workspace header into *sticky (one
 // workgroup; ordered on the stream after the kernels whose give-ups it keeps).
 __global__ void k_keep_error(const u32* __restrict__ ws_error, u32* __restrict__ sticky) {

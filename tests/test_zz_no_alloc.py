@@ -33,7 +33,10 @@ def _both(env, oracle, variant, flags, v, prev):
     st = torch.cuda.current_stream().cuda_stream
     rc = lib.svbgpu_decode_static(variant, flags, d_in.data_ptr(), out.data_ptr(), n, prev, used.data_ptr(), st)
     assert rc == 0, lib.svbgpu_strerror(rc)
+    err = torch.full((1,), 7, dtype=torch.int32, device="cuda:0")
+    assert lib.svbgpu_static_status(err.data_ptr(), st) == 0   # the scratch's error word, without a workspace pointer
     torch.cuda.synchronize()
+    assert int(err.item()) == 0, "a bounded spin of the static-scratch decode gave up"
     assert bool((out[n:] == -1).all()), "wrote past the output"
     return to_np(out[:n], np.uint32), to_np(ref, np.uint32), int(used.item()), int(used_ref.item()), s.size
 
@@ -61,3 +64,4 @@ def test_static_scratch_limits(env):
     assert rc == -6 and b"static scratch" in lib.svbgpu_strerror(rc)
     assert lib.svbgpu_decode_static(0, 0, None, None, 0, 0, None, st) == 0       # empty stream: nothing to do
     assert lib.svbgpu_decode_static(7, 0, dummy.data_ptr(), dummy.data_ptr(), 4, 0, None, st) == -1
+    assert lib.svbgpu_static_status(None, st) == -1
