@@ -120,6 +120,11 @@ int svbgpu_build_has(const char *feature);
  *   "batch_lists_per_wave" = k  only with "batch_chunk" 0: a workgroup per 4k
  *                               streams (default 8); 0: one grid that fills the
  *                               device, streams strided over it
+ *   "host_pointers_only" = 1    the caller promises that the reference-named
+ *                               functions only ever get host memory: they then
+ *                               skip asking the HIP runtime what kind of pointer
+ *                               each argument is (0.1-0.3 us per pointer, more
+ *                               than a dozen values take to code); default 0
  *   "host_cpu_cutoff" = n       host-pointer calls of the reference-named
  *                               functions with fewer than n values (default
  *                               65 536) run on the calling thread (SSE4.1 / SSSE3

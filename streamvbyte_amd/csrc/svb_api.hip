@@ -125,7 +125,7 @@ struct Options {
 };
 std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
     o_encode_qw{4}, o_encode_pipeline{1}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
-    o_host_stage_pageable{1}, o_nt_threshold_mib{128}, o_nt_force{-1};
+    o_host_stage_pageable{1}, o_nt_threshold_mib{128}, o_nt_force{-1}, o_host_pointers_only{0};
 inline Options options() {
   Options o;
   const auto rl = std::memory_order_relaxed;
@@ -494,6 +494,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"nt_threshold_mib", &o_nt_threshold_mib, [](int v) { return v >= -1; }},
       {"nt_force", &o_nt_force, [](int v) { return v >= -1 && v <= 3; }},
       {"host_cpu_cutoff", &o_host_cpu_cutoff, [](int v) { return v >= 0; }},
+      {"host_pointers_only", &o_host_pointers_only, [](int v) { return v == 0 || v == 1; }},
       {"host_serialize", &o_host_serialize, [](int v) { return v == 0 || v == 1; }},
       {"host_stage_pageable", &o_host_stage_pageable, [](int v) { return v == 0 || v == 1; }},
   };
@@ -1097,11 +1098,26 @@ bool is_pinned_host(const void* p) {
 // has no gfx950 device, in which case the host codec is all there is (the
 // reference never fails: include/streamvbyte.h:64 there).  The svbgpu_* API
 // never takes this path.
+// What the probe costs: hipPointerGetAttributes is a lock and a search of the runtime's allocation map,
+// 0.1-0.3 us a pointer -- more than the host codec needs for a dozen values.  A process without any HIP
+// device skips it (nothing can be a device pointer there; the count is asked once), and a caller that
+// only ever passes host memory can say so: svbgpu_set_option("host_pointers_only", 1).
+bool process_has_devices() {
+  static const bool any = [] {
+    int n = 0;
+    const bool ok = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+  }();
+  return any;
+}
 bool run_on_host(size_t count, std::initializer_list<const void*> ptrs) {
-  for (const void* p : ptrs)
-    if (is_device_ptr(p)) return false;
-  if (!dev_info().ok) return true;
-  return count < (size_t)o_host_cpu_cutoff.load(std::memory_order_relaxed);
+  if (!process_has_devices()) return true;
+  if (!o_host_pointers_only.load(std::memory_order_relaxed))
+    for (const void* p : ptrs)
+      if (is_device_ptr(p)) return false;
+  if (count < (size_t)o_host_cpu_cutoff.load(std::memory_order_relaxed)) return true;
+  return !dev_info().ok;
 }
 
 // Host <-> device copies of the host-pointer API.  HIP never sees a pageable

@@ -9,8 +9,9 @@
 // src/streamvbytedelta_encode.c:39-76, src/streamvbytedelta_decode.c:34-74,
 // src/streamvbyte_zigzag.c:3-38).  Two tiers:
 //   * portable scalar loops (any x86-64 / any host), and
-//   * an SSSE3 decoder for whole groups of four values (one byte shuffle per
-//     group, masks built at first use from the width rule, not stored tables),
+//   * SSE4.1 / SSSE3 coders for whole groups of four values (one byte shuffle per
+//     group, masks built at first use from the width rule, not stored tables), and
+//   * AVX-512 coders for blocks of sixteen values (one byte compress / expand per block),
 //     chosen at run time with __builtin_cpu_supports.
 // Buffer rules as in the reference: decoders may read up to 16 bytes past the
 // stream (STREAMVBYTE_PADDING) and write exactly `count` values; encoders write
@@ -274,6 +275,104 @@ __attribute__((target("ssse3"))) uint32_t decode_groups_ssse3(const uint8_t*& ke
   data = d;
   return groups * 4;
 }
+
+// ---- AVX-512 (VBMI2) encode / decode of sixteen values at a time ----------------------------
+// Where the CPU has byte compress / expand (vpcompressb, vpexpandb: Ice Lake and later, Zen 4 and
+// later) a block of sixteen values is ONE such instruction: the encoder keeps byte b of a value iff
+// b < its length (a 64-bit byte mask from one compare) and compresses the 64 bytes; the decoder turns
+// four key bytes into the same 64-bit mask with a bit deposit and a few 64-bit logic operations, loads
+// exactly popcount(mask) bytes (masked load: nothing past the stream is touched) and expands them.  No
+// shuffle tables; the chain from block to block is a popcount and an add.  Same bytes as the scalar
+// rule above (reference src/streamvbyte_encode.c:14-62, src/streamvbyte_decode.c:18-60,
+// src/streamvbyte_0124_encode.c:12-57, src/streamvbyte_0124_decode.c:38-79), checked against the oracle.
+#define SVBCPU_AVX512 __attribute__((target("avx512f,avx512bw,avx512vl,avx512cd,avx512vbmi2,bmi2,popcnt")))
+inline bool have_avx512() {
+  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                         __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512cd") &&
+                         __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("bmi2") &&
+                         __builtin_cpu_supports("popcnt");
+  return ok;
+}
+// Encodes the whole blocks of sixteen values of in[0 .. count); returns the number of values done.
+// A 64-byte store per block stays inside the 4 bytes per value the output buffer holds for the values
+// of this and the following blocks (a block is only taken when sixteen values remain).
+template <int V, bool DELTA>
+SVBCPU_AVX512 uint32_t encode_blocks_avx512(const uint32_t* in, uint32_t count, uint8_t*& keys, uint8_t*& data,
+                                            uint32_t& prev) {
+  const uint32_t blocks = count / 16;
+  const __m512i byte_idx = _mm512_set1_epi32(0x03020100);
+  const __m512i rep = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 8, 8, 12, 12, 12, 12));
+  __m512i before = _mm512_set1_epi32((int)prev);
+  uint8_t* d = data;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    __m512i v = _mm512_loadu_si512(in + 16 * (size_t)b);
+    if (DELTA) {
+      const __m512i shifted = _mm512_alignr_epi32(v, before, 15);  // {prev, v0, .., v14}
+      before = v;
+      v = _mm512_sub_epi32(v, shifted);
+    }
+    __m512i code, len;
+    if (V == k1234) {  // code = (index of the highest set bit of v | 1) / 8, length = code + 1
+      code = _mm512_srli_epi32(_mm512_sub_epi32(_mm512_set1_epi32(31), _mm512_lzcnt_epi32(_mm512_or_si512(v, _mm512_set1_epi32(1)))), 3);
+      len = _mm512_add_epi32(code, _mm512_set1_epi32(1));
+    } else {  // bytes needed = (39 - lzcnt) / 8 (0 for 0); code = min(bytes, 3); length = 0, 1, 2, 4
+      const __m512i nbytes = _mm512_srli_epi32(_mm512_sub_epi32(_mm512_set1_epi32(39), _mm512_lzcnt_epi32(v)), 3);
+      code = _mm512_min_epu32(nbytes, _mm512_set1_epi32(3));
+      len = _mm512_add_epi32(code, _mm512_srli_epi32(_mm512_add_epi32(code, _mm512_set1_epi32(1)), 2));
+    }
+    const __mmask64 keep = _mm512_cmplt_epu8_mask(byte_idx, _mm512_shuffle_epi8(len, rep));
+    _mm512_storeu_si512(d, _mm512_maskz_compress_epi8(keep, v));
+    d += (unsigned)_mm_popcnt_u64(keep);
+    // sixteen codes, one per byte, to four key bytes: the low two bits of every byte, gathered
+    const __m128i c8 = _mm512_cvtepi32_epi8(code);
+    const uint32_t k4 = (uint32_t)_pext_u64((uint64_t)_mm_cvtsi128_si64(c8), 0x0303030303030303ull) |
+                        ((uint32_t)_pext_u64((uint64_t)_mm_extract_epi64(c8, 1), 0x0303030303030303ull) << 16);
+    std::memcpy(keys + 4 * (size_t)b, &k4, 4);
+  }
+  if (DELTA && blocks) prev = in[16 * (size_t)blocks - 1];
+  keys += 4 * (size_t)blocks;
+  data = d;
+  return blocks * 16;
+}
+// The byte mask of sixteen values from their four key bytes: nibble j holds one bit per data byte of value j.
+template <int V>
+SVBCPU_AVX512 inline uint64_t block_mask(uint32_t k4) {
+  const uint64_t c = _pdep_u64(k4, 0x3333333333333333ull);  // code of value j in nibble j
+  const uint64_t lo = c & 0x1111111111111111ull, hi = (c >> 1) & 0x1111111111111111ull, both = lo & hi;
+  if (V == k1234) return 0x1111111111111111ull | ((lo | hi) << 1) | (hi << 2) | (both << 3);  // 1, 3, 7, 15
+  return (lo | hi) | (hi << 1) | (both << 2) | (both << 3);                                     // 0, 1, 3, 15
+}
+// Decodes the whole blocks of sixteen values; returns the number of values done.
+template <int V, bool DELTA>
+SVBCPU_AVX512 uint32_t decode_blocks_avx512(const uint8_t*& keys, const uint8_t*& data, uint32_t* out, uint32_t count,
+                                            uint32_t& prev) {
+  const uint32_t blocks = count / 16;
+  const __m512i zero = _mm512_setzero_si512(), last = _mm512_set1_epi32(15);
+  __m512i run = _mm512_set1_epi32((int)prev);
+  const uint8_t* d = data;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    uint32_t k4;
+    std::memcpy(&k4, keys + 4 * (size_t)b, 4);
+    const uint64_t m = block_mask<V>(k4);
+    const unsigned n = (unsigned)_mm_popcnt_u64(m);
+    const __mmask64 have = n >= 64 ? ~0ull : ((1ull << n) - 1);
+    __m512i v = _mm512_maskz_expand_epi8(m, _mm512_maskz_loadu_epi8(have, d));
+    d += n;
+    if (DELTA) {  // inclusive prefix sum over the sixteen lanes, then the carry of the block before
+      v = _mm512_add_epi32(v, _mm512_alignr_epi32(v, zero, 15));
+      v = _mm512_add_epi32(v, _mm512_alignr_epi32(v, zero, 14));
+      v = _mm512_add_epi32(v, _mm512_alignr_epi32(v, zero, 12));
+      v = _mm512_add_epi32(v, _mm512_alignr_epi32(v, zero, 8));
+      v = _mm512_add_epi32(v, run);
+      run = _mm512_permutexvar_epi32(last, v);
+    }
+    _mm512_storeu_si512(out + 16 * (size_t)b, v);
+  }
+  if (DELTA && blocks) prev = out[16 * (size_t)blocks - 1];
+  keys += 4 * (size_t)blocks;
+  data = d;
+  return blocks * 16;
+}
 #endif
 
 template <int V, bool DELTA>
@@ -284,7 +383,8 @@ size_t decode(const uint8_t* in, uint32_t* out, uint32_t count, uint32_t prev) {
   const uint8_t* data = in + keylen;
   uint32_t done = 0;
 #if defined(__x86_64__)
-  if (count >= 8 && have_ssse3()) done = decode_groups_ssse3<V, DELTA>(keys, data, out, count, prev);
+  if (count >= 32 && have_avx512()) done = decode_blocks_avx512<V, DELTA>(keys, data, out, count, prev);
+  if (count - done >= 8 && have_ssse3()) done += decode_groups_ssse3<V, DELTA>(keys, data, out + done, count - done, prev);
 #endif
   data = decode_scalar_from<V, DELTA>(keys, data, out, done, count, prev);
   return (size_t)(data - in);
@@ -298,7 +398,8 @@ size_t encode(const uint32_t* in, uint32_t count, uint8_t* out, uint32_t prev) {
   uint8_t* data = out + keylen;
   uint32_t done = 0;
 #if defined(__x86_64__)
-  if (count >= 8 && have_sse41()) done = encode_groups_sse41<V, DELTA>(in, count, keys, data, prev);
+  if (count >= 32 && have_avx512()) done = encode_blocks_avx512<V, DELTA>(in, count, keys, data, prev);
+  if (count - done >= 8 && have_sse41()) done += encode_groups_sse41<V, DELTA>(in + done, count - done, keys, data, prev);
 #endif
   data = encode_scalar_from<V, DELTA>(in, done, count, keys, data, prev);
   return (size_t)(data - out);
