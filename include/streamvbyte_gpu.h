@@ -123,8 +123,12 @@ int svbgpu_build_has(const char *feature);
  *   "host_pointers_only" = 1    the caller promises that the reference-named
  *                               functions only ever get host memory: they then
  *                               skip asking the HIP runtime what kind of pointer
- *                               each argument is (0.1-0.3 us per pointer, more
- *                               than a dozen values take to code); default 0
+ *                               each argument is (about 0.1 us per pointer, more
+ *                               than a hundred values take to code; arguments on
+ *                               the calling thread's stack are never asked about);
+ *                               default 0.  SVB_HOST_POINTERS_ONLY=1 in the
+ *                               environment does the same for a program that
+ *                               cannot be changed
  *   "host_cpu_cutoff" = n       host-pointer calls of the reference-named
  *                               functions with fewer than n values (default
  *                               65 536) run on the calling thread (SSE4.1 / SSSE3

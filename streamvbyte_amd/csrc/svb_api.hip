@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <pthread.h>
 #include <string>
 #include <vector>
 
@@ -1101,7 +1102,8 @@ bool is_pinned_host(const void* p) {
 // What the probe costs: hipPointerGetAttributes is a lock and a search of the runtime's allocation map,
 // 0.1-0.3 us a pointer -- more than the host codec needs for a dozen values.  A process without any HIP
 // device skips it (nothing can be a device pointer there; the count is asked once), and a caller that
-// only ever passes host memory can say so: svbgpu_set_option("host_pointers_only", 1).
+// only ever passes host memory can say so: svbgpu_set_option("host_pointers_only", 1), or
+// SVB_HOST_POINTERS_ONLY=1 in the environment of a program that cannot be changed.
 bool process_has_devices() {
   static const bool any = [] {
     int n = 0;
@@ -1111,11 +1113,36 @@ bool process_has_devices() {
   }();
   return any;
 }
+// Memory on the calling thread's own stack is host memory without asking anybody (the reference's
+// own test programs keep their arrays there: tests/perf.c:48-50, tests/unit.c:93-96).
+bool on_own_stack(const void* p) {
+  struct Bounds { uintptr_t lo = 0, hi = 0; };
+  thread_local const Bounds b = [] {
+    Bounds r;
+    pthread_attr_t at;
+    if (pthread_getattr_np(pthread_self(), &at) == 0) {
+      void* addr = nullptr;
+      size_t size = 0;
+      if (pthread_attr_getstack(&at, &addr, &size) == 0) {
+        r.lo = (uintptr_t)addr;
+        r.hi = r.lo + size;
+      }
+      pthread_attr_destroy(&at);
+    }
+    return r;
+  }();
+  const uintptr_t a = (uintptr_t)p;
+  return a >= b.lo && a < b.hi;
+}
+bool host_pointers_only() {
+  static const bool env = [] { const char* e = std::getenv("SVB_HOST_POINTERS_ONLY"); return e && *e && *e != '0'; }();
+  return env || o_host_pointers_only.load(std::memory_order_relaxed) != 0;
+}
 bool run_on_host(size_t count, std::initializer_list<const void*> ptrs) {
   if (!process_has_devices()) return true;
-  if (!o_host_pointers_only.load(std::memory_order_relaxed))
+  if (!host_pointers_only())
     for (const void* p : ptrs)
-      if (is_device_ptr(p)) return false;
+      if (!on_own_stack(p) && is_device_ptr(p)) return false;
   if (count < (size_t)o_host_cpu_cutoff.load(std::memory_order_relaxed)) return true;
   return !dev_info().ok;
 }

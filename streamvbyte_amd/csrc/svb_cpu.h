@@ -279,9 +279,9 @@ __attribute__((target("ssse3"))) uint32_t decode_groups_ssse3(const uint8_t*& ke
 // ---- AVX-512 (VBMI2) encode / decode of sixteen values at a time ----------------------------
 // Where the CPU has byte compress / expand (vpcompressb, vpexpandb: Ice Lake and later, Zen 4 and
 // later) a block of sixteen values is ONE such instruction: the encoder keeps byte b of a value iff
-// b < its length (a 64-bit byte mask from one compare) and compresses the 64 bytes; the decoder turns
-// four key bytes into the same 64-bit mask with a bit deposit and a few 64-bit logic operations, loads
-// exactly popcount(mask) bytes (masked load: nothing past the stream is touched) and expands them.  No
+// b < its length (a 64-bit byte mask from one compare) and compresses the 64 bytes; the decoder makes
+// the same mask from the block's four key bytes, loads exactly popcount(mask) bytes (masked load:
+// nothing past the stream is touched) and expands them.  No
 // shuffle tables; the chain from block to block is a popcount and an add.  Same bytes as the scalar
 // rule above (reference src/streamvbyte_encode.c:14-62, src/streamvbyte_decode.c:18-60,
 // src/streamvbyte_0124_encode.c:12-57, src/streamvbyte_0124_decode.c:38-79), checked against the oracle.
@@ -334,28 +334,30 @@ SVBCPU_AVX512 uint32_t encode_blocks_avx512(const uint32_t* in, uint32_t count, 
   data = d;
   return blocks * 16;
 }
-// The byte mask of sixteen values from their four key bytes: nibble j holds one bit per data byte of value j.
-template <int V>
-SVBCPU_AVX512 inline uint64_t block_mask(uint32_t k4) {
-  const uint64_t c = _pdep_u64(k4, 0x3333333333333333ull);  // code of value j in nibble j
-  const uint64_t lo = c & 0x1111111111111111ull, hi = (c >> 1) & 0x1111111111111111ull, both = lo & hi;
-  if (V == k1234) return 0x1111111111111111ull | ((lo | hi) << 1) | (hi << 2) | (both << 3);  // 1, 3, 7, 15
-  return (lo | hi) | (hi << 1) | (both << 2) | (both << 3);                                     // 0, 1, 3, 15
-}
-// Decodes the whole blocks of sixteen values; returns the number of values done.
+// Decodes the whole blocks of sixteen values; returns the number of values done.  The byte mask of a
+// block comes from its four key bytes in five vector instructions: the sixteen 2-bit codes spread over
+// the 32-bit lanes (broadcast + variable shift), their lengths looked up and copied to the four bytes
+// of each lane (two byte shuffles), and byte b of a lane is present iff b < length.
 template <int V, bool DELTA>
 SVBCPU_AVX512 uint32_t decode_blocks_avx512(const uint8_t*& keys, const uint8_t*& data, uint32_t* out, uint32_t count,
                                             uint32_t& prev) {
   const uint32_t blocks = count / 16;
-  const __m512i zero = _mm512_setzero_si512(), last = _mm512_set1_epi32(15);
+  const __m512i zero = _mm512_setzero_si512(), last = _mm512_set1_epi32(15), three = _mm512_set1_epi32(3);
+  const __m512i shifts = _mm512_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30);
+  const __m512i byte_idx = _mm512_set1_epi32(0x03020100);
+  const __m512i rep = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 8, 8, 12, 12, 12, 12));
+  const __m512i lens = _mm512_broadcast_i32x4(V == k1234 ? _mm_setr_epi8(1, 2, 3, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+                                                         : _mm_setr_epi8(0, 1, 2, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0));
   __m512i run = _mm512_set1_epi32((int)prev);
   const uint8_t* d = data;
   for (uint32_t b = 0; b < blocks; ++b) {
     uint32_t k4;
     std::memcpy(&k4, keys + 4 * (size_t)b, 4);
-    const uint64_t m = block_mask<V>(k4);
+    const __m512i code = _mm512_and_si512(_mm512_srlv_epi32(_mm512_set1_epi32((int)k4), shifts), three);
+    const __m512i lenrep = _mm512_shuffle_epi8(lens, _mm512_shuffle_epi8(code, rep));
+    const __mmask64 m = _mm512_cmplt_epu8_mask(byte_idx, lenrep);
     const unsigned n = (unsigned)_mm_popcnt_u64(m);
-    const __mmask64 have = n >= 64 ? ~0ull : ((1ull << n) - 1);
+    const __mmask64 have = _bzhi_u64(~0ull, n);  // the low n bits (all 64 for n = 64): nothing past the stream is read
     __m512i v = _mm512_maskz_expand_epi8(m, _mm512_maskz_loadu_epi8(have, d));
     d += n;
     if (DELTA) {  // inclusive prefix sum over the sixteen lanes, then the carry of the block before
