@@ -290,10 +290,15 @@ int svbgpu_decode_intersect(int variant, const uint8_t *d_in, uint32_t count, ui
 static inline size_t svbgpu_max_compressedbytes64(uint32_t count) {
   return ((size_t)count + 3) / 4 + 8 * (size_t)count + SVBGPU_PADDING64;
 }
-int svbgpu_encode64(const uint64_t *d_in, uint32_t count, uint8_t *d_out, void *d_workspace,
-                    size_t workspace_bytes, uint64_t *d_written, void *stream);
-int svbgpu_decode64(const uint8_t *d_in, uint64_t *d_out, uint32_t count, void *d_workspace,
-                    size_t workspace_bytes, uint64_t *d_consumed, void *stream);
+/* flags: SVBGPU_DELTA codes value - previous value (mod 2^64, seed `prev`) and decodes by running
+ * sums; SVBGPU_ZIGZAG maps through (v << 1) ^ (0 - (v >> 63)) before coding and back after decoding;
+ * both together code the zigzag of the difference.  The encoder is one pass over the values (tile
+ * offsets by decoupled look-back, as for 32-bit values); the differential decoder reads the stream
+ * twice (value sums per 4096 values first).  No batched form. */
+int svbgpu_encode64(unsigned flags, const uint64_t *d_in, uint32_t count, uint8_t *d_out, uint64_t prev,
+                    void *d_workspace, size_t workspace_bytes, uint64_t *d_written, void *stream);
+int svbgpu_decode64(unsigned flags, const uint8_t *d_in, uint64_t *d_out, uint32_t count, uint64_t prev,
+                    void *d_workspace, size_t workspace_bytes, uint64_t *d_consumed, void *stream);
 
 /*
  * Batched entry points: `nstreams` independent streams in one launch (posting

@@ -279,7 +279,7 @@ class DeviceCodec:
                    "svbgpu_decode")
         return out, self.res[1:2]
 
-    def encode64(self, values, out=None):
+    def encode64(self, values, out=None, flags=0, prev=0):
         """int64 tensor (the uint64 bits) -> 1248 stream; returns (out_bytes, size_tensor[1])."""
         torch = self.torch
         n = values.numel()
@@ -287,19 +287,21 @@ class DeviceCodec:
         if out is None:
             out = torch.empty((n + 3) // 4 + 8 * n + 32, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.svbgpu_encode64(values.data_ptr(), n, out.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
-                                            self._res_ptr(0), self._stream()), "svbgpu_encode64")
+            _check(self.lib.svbgpu_encode64(flags, values.data_ptr(), n, out.data_ptr(), prev & 0xFFFFFFFFFFFFFFFF,
+                                            self.ws.data_ptr(), self.ws_bytes, self._res_ptr(0), self._stream()),
+                   "svbgpu_encode64")
         return out, self.res[0:1]
 
-    def decode64(self, stream, count, out=None):
+    def decode64(self, stream, count, out=None, flags=0, prev=0):
         """1248 stream (readable 32 B past its end) -> int64 tensor; returns (values, consumed_tensor[1])."""
         torch = self.torch
         assert count <= self.max_count and stream.is_contiguous()
         if out is None:
             out = torch.empty(count, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.svbgpu_decode64(stream.data_ptr(), out.data_ptr(), count, self.ws.data_ptr(), self.ws_bytes,
-                                            self._res_ptr(1), self._stream()), "svbgpu_decode64")
+            _check(self.lib.svbgpu_decode64(flags, stream.data_ptr(), out.data_ptr(), count, prev & 0xFFFFFFFFFFFFFFFF,
+                                            self.ws.data_ptr(), self.ws_bytes, self._res_ptr(1), self._stream()),
+                   "svbgpu_decode64")
         return out, self.res[1:2]
 
     def quantize_encode(self, values, scale, out=None, variant=V0124):

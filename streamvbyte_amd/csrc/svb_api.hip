@@ -861,8 +861,9 @@ int svbgpu_decode_intersect(int variant, const uint8_t* d_in, uint32_t count, ui
   return SVBGPU_OK;
 }
 
-int svbgpu_encode64(const uint64_t* d_in, uint32_t count, uint8_t* d_out, void* ws, size_t ws_bytes,
-                    uint64_t* d_written, void* stream) {
+int svbgpu_encode64(unsigned flags, const uint64_t* d_in, uint32_t count, uint8_t* d_out, uint64_t prev, void* ws,
+                    size_t ws_bytes, uint64_t* d_written, void* stream) {
+  if (bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
     if (d_written) { int rc0 = fill_u32(d_written, 0u, 8, S(stream)); if (rc0) return rc0; }
     return SVBGPU_OK;
@@ -871,20 +872,29 @@ int svbgpu_encode64(const uint64_t* d_in, uint32_t count, uint8_t* d_out, void* 
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
+  rc = clear_lookback(count, ws, S(stream));
+  if (rc) return rc;
   const WsLayout L = ws_layout(count);
-  // the values are read twice, 8 bytes each: beyond the cache, neither pass leaves the other anything to find
-  SVB_NT_SWITCH_01(nt_policy(options(), 8ull * count, 0) ? 1 : 0, NTV, {
-    hipLaunchKernelGGL(k_sizes64<NTV>, dim3(L.n_mega), dim3(1024), 0, S(stream), d_in, count, ws_at<u32>(ws, L.off_wt_rel),
-                       ws_at<u32>(ws, L.off_mega_sum), L.wt_per_mega);
-    hipLaunchKernelGGL(k_encode64<NTV>, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0, S(stream), d_in,
-                       count, d_out, ws_dir(ws, L), d_written);
-  })
+  constexpr int NW = 8;  // wave tiles per look-back tile
+  const unsigned n_tiles = (unsigned)((L.n_wt + NW - 1) / NW);
+  const unsigned grid = stream_grid(n_tiles, 2);
+  const LbWords lbw{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+  const Options o = options();
+  const bool d = flags & SVBGPU_DELTA, z = flags & SVBGPU_ZIGZAG;
+#define SVB_ENC64(D, Z)                                                                                              \
+  SVB_NT_SWITCH_013(nt_policy(o, 8ull * count, (count + 3ull) / 4 + count), NTV,                                     \
+                    hipLaunchKernelGGL((k_encode64_lb<D, Z, NW, NTV>), dim3(grid), dim3(NW * 64), 0, S(stream), d_in, \
+                                       count, n_tiles, d_out, (u64)prev, ws_hdr(ws), lbw, d_written))
+  if (d) { if (z) SVB_ENC64(true, true) else SVB_ENC64(true, false) }
+  else   { if (z) SVB_ENC64(false, true) else SVB_ENC64(false, false) }
+#undef SVB_ENC64
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }
 
-int svbgpu_decode64(const uint8_t* d_in, uint64_t* d_out, uint32_t count, void* ws, size_t ws_bytes,
-                    uint64_t* d_consumed, void* stream) {
+int svbgpu_decode64(unsigned flags, const uint8_t* d_in, uint64_t* d_out, uint32_t count, uint64_t prev, void* ws,
+                    size_t ws_bytes, uint64_t* d_consumed, void* stream) {
+  if (bad_flags(flags)) return SVBGPU_EINVAL;
   if (count == 0) {
     if (d_consumed) { int rc0 = fill_u32(d_consumed, 0u, 8, S(stream)); if (rc0) return rc0; }
     return SVBGPU_OK;
@@ -896,9 +906,27 @@ int svbgpu_decode64(const uint8_t* d_in, uint64_t* d_out, uint32_t count, void* 
   rc = build_directory(SVBGPU_1248, d_in, count, ws, S(stream));
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
-  SVB_NT_SWITCH_023(nt_policy(options(), 0, 8ull * count) & kNtStores, NTV,
-                    hipLaunchKernelGGL(k_decode64<NTV>, dim3((unsigned)((L.n_wt + kWaves - 1) / kWaves)), dim3(kBlock), 0,
-                                       S(stream), d_in, d_out, count, ws_dir(ws, L), d_consumed))
+  const unsigned grid = (unsigned)((L.n_wt + kWaves - 1) / kWaves);
+  const bool d = flags & SVBGPU_DELTA, z = flags & SVBGPU_ZIGZAG;
+  const Dir dir = ws_dir(ws, L);
+  // differential: value sums per workgroup of four wave tiles (8 bytes each, in the room of the 32-bit
+  // decoder's per-wave-tile sums), scanned in place, then the decoder adds them up
+  u64* wg = ws_at<u64>(ws, L.off_wt_vsum);
+  if (d) {
+    u64* blk = ws_at<u64>(ws, L.off_blk);
+    const unsigned nblk = (grid + 4095) / 4096;
+    if (z) hipLaunchKernelGGL(k_value_sums64<true>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count, dir, wg);
+    else hipLaunchKernelGGL(k_value_sums64<false>, dim3(grid), dim3(kBlock), 0, S(stream), d_in, count, dir, wg);
+    hipLaunchKernelGGL(k_block_sums64, dim3(nblk), dim3(1024), 0, S(stream), wg, (u64)grid, blk);
+    hipLaunchKernelGGL(k_multi_offsets, dim3(nblk), dim3(1024), 0, S(stream), wg, (u64)grid, blk, wg);
+  }
+#define SVB_DEC64(D, Z)                                                                                          \
+  SVB_NT_SWITCH_023(nt_policy(options(), 0, 8ull * count) & kNtStores, NTV,                                      \
+                    hipLaunchKernelGGL((k_decode64<D, Z, NTV>), dim3(grid), dim3(kBlock), 0, S(stream), d_in, d_out, \
+                                       count, dir, d_consumed, (u64)prev, wg))
+  if (d) { if (z) SVB_DEC64(true, true) else SVB_DEC64(true, false) }
+  else   { if (z) SVB_DEC64(false, true) else SVB_DEC64(false, false) }
+#undef SVB_DEC64
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

@@ -8,12 +8,12 @@
 // places; a wave tile's own place comes from the same two-level directory as the 32-bit
 // decoders (Dir):
 //   decode:  k_key_sums<V1248> over the key block, then k_decode64;
-//   encode:  k_sizes64 over the VALUES (the sizes are not known before), then k_encode64.
-// The encoder therefore reads its input twice (16 + 0.25 + dbar bytes per value instead of
-// 8 + 0.25 + dbar): a first, plain implementation -- the look-back encoder of the 32-bit
-// path is the model for a single-pass one.
+//   encode:  k_encode64_lb, one pass: the tile offsets come from the same decoupled look-back as
+//            the 32-bit encoder's, the bytes are assembled in an LDS image.
 #pragma once
 #include "svb_decode.h"
+#include "svb_encode.h"
+#include "svb_lists.h"
 
 namespace svb {
 
@@ -30,102 +30,207 @@ __device__ __forceinline__ u32 group_len64(u32 key, u32 nv) {
 }
 
 // ---------------------------------------------------------------------------
-// k_sizes64: the encoder's directory.  One workgroup of 1024 threads per mega tile;
-// a round takes 16 wave tiles, one per wave (8 loads of 16 bytes per lane), sums the
-// widths, and wave 0 lays the 16 sums behind the mega tile's running offset.
-template <int NT = 0>
-__global__ __launch_bounds__(1024) void k_sizes64(const u64* __restrict__ in, u32 count, u32* __restrict__ wt_rel,
-                                                  u32* __restrict__ mega_sum, u32 wt_per_mega) {
-  __shared__ u32 s_sum[2][16];
-  const int lane = lane_id(), wave = wave_id();
-  const u64 n_wt = ((u64)count + kWtInts - 1) / kWtInts;
-  const u64 wt0 = (u64)blockIdx.x * wt_per_mega, wt1 = min(n_wt, wt0 + wt_per_mega);
-  u32 base = 0;
-  int buf = 0;
-  for (u64 wtb = wt0; wtb < wt1; wtb += 16) {
-    const u64 wt = wtb + wave;
-    u32 s = 0;
-    if (wt < wt1) {
-      const u64 first = wt * kWtInts;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {  // values first + 2 * (64 i + lane), + 1
-        const u64 idx = first + 2ull * (64 * i + lane);
-        u64 a = 0, b = 0;
-        if (idx + 1 < count) {
-          const uint4 p = ld_stream16<(NT & kNtLoads) != 0>(in + idx);
-          a = ((u64)p.y << 32) | p.x; b = ((u64)p.w << 32) | p.z;
-          s += (1u << code64(a)) + (1u << code64(b));
-        } else if (idx < count) {
-          s += 1u << code64(in[idx]);
-        }
-      }
-    }
-    s = wave_sum(s);
-    if (lane == 0) s_sum[buf][wave] = s;
-    __syncthreads();
-    if (wave == 0) {
-      const u32 x = lane < 16 ? s_sum[buf][lane] : 0u;
-      const u32 incl = wave_scan_incl(x, lane);
-      if (lane < 16 && wtb + lane < wt1) wt_rel[wtb + lane] = base + incl - x;
-      base += wave_last(incl);
-    }
-    buf ^= 1;
-  }
-  if (threadIdx.x == 0) mega_sum[blockIdx.x] = base;
+// k_encode64_lb: the single-pass encoder.  The 32-bit encoder's tile cycle (k_encode in
+// svb_encode.h) on 64-bit values: persistent workgroups draw tiles of NW wave tiles from the
+// ticket; a wave loads its wave tile once (lane l of step s holds group 64 s + l: two 16-byte
+// loads), classifies, the tile's byte count goes through the two-level look-back, and the bytes
+// are assembled in a wave-private LDS image laid out on the 16-byte grid of the destination and
+// copied out with aligned 16-byte stores.  8 + 0.25 + dbar bytes per value.
+struct __align__(16) EncWaveLds64 {
+  u8 data[2 * kWtDataMax + 64];  // image of one wave tile's data bytes (+16 alignment shift, +36 store overhang)
+  u8 keys[kWtKeys];
+};
+typedef unsigned __int128 u128;
+__device__ __forceinline__ u64 zz_enc64(u64 v) { return (v << 1) ^ (0ull - (v >> 63)); }
+__device__ __forceinline__ u64 zz_dec64(u64 v) { return (v >> 1) ^ (0ull - (v & 1ull)); }
+// The data bytes of a group, value 0 first, as eight dwords (values are below 256^len, absent ones zero).
+__device__ __forceinline__ void pack_group64(const u64 (&x)[4], const u32 (&len)[4], u32 (&d)[8]) {
+  const u128 lo = (u128)x[0] | ((u128)x[1] << (8u * len[0]));  // len[0] <= 8
+  const u128 hi = (u128)x[2] | ((u128)x[3] << (8u * len[2]));
+  const u32 s = len[0] + len[1];                                // 0..16 bytes taken by values 0 and 1
+  const u128 low = s >= 16u ? lo : (lo | (hi << (8u * s)));
+  const u128 high = s >= 16u ? hi : (s == 0u ? (u128)0 : (hi >> (128u - 8u * s)));
+  d[0] = (u32)low; d[1] = (u32)(low >> 32); d[2] = (u32)(low >> 64); d[3] = (u32)(low >> 96);
+  d[4] = (u32)high; d[5] = (u32)(high >> 32); d[6] = (u32)(high >> 64); d[7] = (u32)(high >> 96);
 }
-
-// ---------------------------------------------------------------------------
-// k_encode64: a wave per wave tile.  Lane l of step s holds group 64 s + l: two 16-byte
-// loads, four width codes, a wave scan of the group lengths, then every value stored at
-// its own byte address in exactly its own length (1, 2, 4 or 8 bytes).
-template <int NT = 0>
-__global__ __launch_bounds__(kBlock) void k_encode64(const u64* __restrict__ in, u32 count, u8* __restrict__ out,
-                                                     Dir dir, u64* __restrict__ written) {
+template <bool DELTA, bool ZZ, int NW, int NT>
+__global__ __launch_bounds__(NW * 64, 4) void k_encode64_lb(const u64* __restrict__ in, u32 count, u32 n_tiles,
+                                                           u8* __restrict__ out, u64 prev, WsHeader* __restrict__ hdr,
+                                                           LbWords lb, u64* __restrict__ written) {
+  __shared__ EncWaveLds64 s_lds[NW];
+  __shared__ u32 s_wave_tot[NW];
+  __shared__ u64 s_prefix;
+  __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
   const u64 keylen = ((u64)count + 3) >> 2;
-  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
-  const u32 wt = blockIdx.x * kWaves + wave;
-  if (wt >= n_wt) return;
-  u64 doff = dir_offset(dir, wt, lane);
-  u8* data = out + keylen;
-#pragma unroll 1
-  for (int step = 0; step < 4; ++step) {
-    const u64 g = (u64)wt * kWtKeys + 64 * step + lane;  // group = key index
-    const u64 first = 4 * g;
-    const u32 nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
-    u64 v[4] = {0, 0, 0, 0};
-    if (nv == 4u) {
-      const uint4 p = ld_stream16<(NT & kNtLoads) != 0>(in + first), q = ld_stream16<(NT & kNtLoads) != 0>(in + first + 2);
-      v[0] = ((u64)p.y << 32) | p.x; v[1] = ((u64)p.w << 32) | p.z;
-      v[2] = ((u64)q.y << 32) | q.x; v[3] = ((u64)q.w << 32) | q.z;
-    } else {
-      for (u32 k = 0; k < nv; ++k) v[k] = in[first + k];
-    }
-    u32 key = 0, len[4], L = 0;
+  u8* data_out = out + keylen;
+  EncWaveLds64& S = s_lds[wave];
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+    __syncthreads();
+    const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
+    if (tile >= n_tiles) break;
+    const u64 wt = (u64)tile * NW + wave;
+    const u64 wt_first = wt * kWtInts;
+
+    // ---- load, transform, classify ------------------------------------------
+    u64 v[4][4];
+    u32 key4 = 0;    // the four keys of this lane, one per step
+    u32 lens4 = 0;   // the four group lengths (0..32), one byte each
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const u32 c = (u32)k < nv ? code64(v[k]) : 0u;
-      key |= c << (2 * k);
-      len[k] = (u32)k < nv ? 1u << c : 0u;
-      L += len[k];
-    }
-    const u32 incl = wave_scan_incl(L, lane);
-    u8* p = data + doff + (incl - L);
-    doff += wave_last(incl);
-    if (nv) {
-      out[g] = (u8)key;
+    for (int step = 0; step < 4; ++step) {
+      const u64 first = wt_first + 4ull * (64 * step + lane);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const u64 x = v[k];
-        if (len[k] == 8u) __builtin_memcpy(p, &x, 8);
-        else if (len[k] == 4u) { const u32 y = (u32)x; __builtin_memcpy(p, &y, 4); }
-        else if (len[k] == 2u) { const unsigned short y = (unsigned short)x; __builtin_memcpy(p, &y, 2); }
-        else if (len[k] == 1u) *p = (u8)x;
-        p += len[k];
+      for (int k = 0; k < 4; ++k) v[step][k] = 0;
+      if (first + 4 <= count) {
+        const uint4 p = ld_stream16<(NT & kNtLoads) != 0>(in + first), q = ld_stream16<(NT & kNtLoads) != 0>(in + first + 2);
+        v[step][0] = ((u64)p.y << 32) | p.x; v[step][1] = ((u64)p.w << 32) | p.z;
+        v[step][2] = ((u64)q.y << 32) | q.x; v[step][3] = ((u64)q.w << 32) | q.z;
+      } else {
+        for (u32 k = 0; k < 4 && first + k < count; ++k) v[step][k] = in[first + k];
       }
     }
+    if (DELTA) {  // value - the value before it (wrap-around); the one before the wave tile's first comes from memory
+      u64 carry = prev;
+      if (wt_first > 0 && wt_first <= count) carry = in[wt_first - 1];
+#pragma unroll
+      for (int step = 0; step < 4; ++step) {
+        const u64 last = v[step][3];
+        const u32 pl = wave_shift_up1((u32)last, (u32)carry), ph = wave_shift_up1((u32)(last >> 32), (u32)(carry >> 32));
+        carry = ((u64)wave_last((u32)(last >> 32)) << 32) | wave_last((u32)last);
+        const u64 before = ((u64)ph << 32) | pl;
+        v[step][3] -= v[step][2]; v[step][2] -= v[step][1]; v[step][1] -= v[step][0]; v[step][0] -= before;
+      }
+    }
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const u64 first = wt_first + 4ull * (64 * step + lane);
+      const u32 nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
+      u32 key = 0, L = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u64 x = v[step][k];
+        if (ZZ) x = zz_enc64(x);
+        if ((u32)k >= nv) x = 0;
+        v[step][k] = x;
+        const u32 c = (u32)k < nv ? code64(x) : 0u;
+        key |= c << (2 * k);
+        L += (u32)k < nv ? 1u << c : 0u;
+      }
+      key4 |= key << (8 * step);
+      lens4 |= L << (8 * step);
+    }
+    const u32 lane_tot = (lens4 & 0xFFu) + ((lens4 >> 8) & 0xFFu) + ((lens4 >> 16) & 0xFFu) + (lens4 >> 24);
+    const u32 wave_tot = wave_sum(lane_tot);
+    if (lane == 0) s_wave_tot[wave] = wave_tot;
+    __syncthreads();
+
+    // ---- tile offset ---------------------------------------------------------
+    if (wave == 0) {
+      u32 tile_tot = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[w];
+      const u64 excl = lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error);
+      if (lane == 0) {
+        s_prefix = excl;
+        if (tile == n_tiles - 1 && written) *written = keylen + excl + tile_tot;
+      }
+    }
+    __syncthreads();
+    u64 doff = s_prefix;
+    for (int w = 0; w < wave; ++w) doff += s_wave_tot[w];
+
+    // ---- places of the groups: scans over the lanes, one 16-bit field per step --------------
+    if (wt_first < count) {
+      const u64 packed = (u64)(lens4 & 0xFFu) | ((u64)((lens4 >> 8) & 0xFFu) << 16) | ((u64)((lens4 >> 16) & 0xFFu) << 32) |
+                         ((u64)(lens4 >> 24) << 48);
+      const u32 inc_lo = wave_scan_incl((u32)packed, lane), inc_hi = wave_scan_incl((u32)(packed >> 32), lane);
+      const u64 incl = ((u64)inc_hi << 32) | inc_lo;
+      const u64 tots = ((u64)wave_last(inc_hi) << 32) | wave_last(inc_lo);
+      const u64 excl = incl - packed;
+      u8* dst = data_out + doff;
+      const u32 a = (u32)((uintptr_t)dst & 15u);  // LDS image byte i + a <-> dst[i]
+      const u32 t0 = (u32)(tots & 0xFFFFu), t1 = (u32)((tots >> 16) & 0xFFFFu), t2 = (u32)((tots >> 32) & 0xFFFFu),
+                t3 = (u32)(tots >> 48);
+      const u32 total = t0 + t1 + t2 + t3;
+      const u32 pj[4] = {a + (u32)(excl & 0xFFFFu), a + t0 + (u32)((excl >> 16) & 0xFFFFu),
+                         a + t0 + t1 + (u32)((excl >> 32) & 0xFFFFu), a + t0 + t1 + t2 + (u32)(excl >> 48)};
+      // Aligned dword stores as in the 32-bit 1234 image (encode_wavetile): steps last first and
+      // dword index by dword index, so that on a border dword the earlier group's tail lands after the
+      // later group's dword 0; the later group's first three bytes are written again afterwards.  Whole
+      // groups have at least four bytes; the one group that may have fewer is the stream's last.
+      u32 head[4];
+#pragma unroll
+      for (int step = 3; step >= 0; --step) {
+        const u32 L = (lens4 >> (8 * step)) & 0xFFu, key = (key4 >> (8 * step)) & 0xFFu;
+        S.keys[step * 64 + lane] = (u8)key;
+        u32 len[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) len[k] = 0;
+        {  // lengths of the present values: the first nv codes count, the others are zero values of length 0
+          const u64 first = wt_first + 4ull * (64 * step + lane);
+          const u32 nv = first < count ? (u32)min((u64)4, (u64)count - first) : 0u;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) len[k] = (u32)k < nv ? 1u << ((key >> (2 * k)) & 3u) : 0u;
+        }
+        u32 d[8];
+        pack_group64(v[step], len, d);
+        const u32 p = pj[step];
+        const u32 sel = shift_selector(p);
+        u32* q = reinterpret_cast<u32*>(S.data + (p & ~3u));
+        const u32 e = L ? L + (p & 3u) : 0u;  // dword I is written iff e > 4 I
+        if (e > 0u) q[0] = __builtin_amdgcn_perm(d[0], 0u, sel);
+#pragma unroll
+        for (int I = 1; I < 8; ++I)
+          if (e > 4u * I) q[I] = __builtin_amdgcn_perm(d[I], d[I - 1], sel);
+        if (e > 32u) q[8] = __builtin_amdgcn_perm(0u, d[7], sel);
+        head[step] = d[0];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int step = 0; step < 4; ++step)
+        if ((lens4 >> (8 * step)) & 0xFFu) {
+          const u32 p = pj[step];
+          S.data[p] = (u8)head[step];
+          S.data[p + 1] = (u8)(head[step] >> 8);
+          S.data[p + 2] = (u8)(head[step] >> 16);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // data: aligned interior chunks, ragged head / tail by bytes
+      {
+        const u32 end = a + total;
+        const u32 c_lo = (a + 15u) >> 4, c_hi = end >> 4;
+        u8* g0 = dst - a;
+        uint4* g16 = reinterpret_cast<uint4*>(g0);
+        const uint4* l16 = reinterpret_cast<const uint4*>(S.data);
+        for (u32 c = c_lo + lane; c < c_hi; c += 64) st_stream16<(NT & kNtStores) != 0>(g16 + c, l16[c]);
+        const u32 hend = min(16u * c_lo, end);
+        const u32 tstart = max(16u * c_hi, hend);
+        if (lane < 16) {
+          const u32 i = a + lane;
+          if (i < hend) g0[i] = S.data[i];
+        } else if (lane < 32) {
+          const u32 i = tstart + (lane - 16);
+          if (i < end) g0[i] = S.data[i];
+        }
+      }
+      // keys
+      {
+        const u64 k0 = wt * kWtKeys;
+        const u32 nkeys = (u32)min((u64)kWtKeys, keylen - k0);
+        u8* kdst = out + k0;
+        if ((((uintptr_t)kdst) & 3u) == 0 && 4u * lane + 4u <= nkeys) {
+          *reinterpret_cast<u32*>(kdst + 4 * lane) = reinterpret_cast<const u32*>(S.keys)[lane];
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (4u * lane + b < nkeys) kdst[4 * lane + b] = S.keys[4 * lane + b];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  if (wt == n_wt - 1 && lane == 0 && written) *written = keylen + doff;
 }
 
 // ---------------------------------------------------------------------------
@@ -147,17 +252,12 @@ __device__ __forceinline__ u64 bytes64_at(const u32 (&d)[8], u32 o, u32 len) {
   const u64 x = ((u64)hi << 32) | lo;
   return len >= 8u ? x : x & ((1ull << (8u * len)) - 1ull);
 }
-template <int NT = 0>
-__global__ __launch_bounds__(kBlock) void k_decode64(const u8* __restrict__ in, u64* __restrict__ out, u32 count,
-                                                     Dir dir, u64* __restrict__ consumed) {
-  const int lane = lane_id(), wave = wave_id();
-  const u64 keylen = ((u64)count + 3) >> 2;
-  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
-  const u32 wt = blockIdx.x * kWaves + wave;
-  if (wt >= n_wt) return;
-  u64 doff = dir_offset(dir, wt, lane);
-  const u8* data = in + keylen;
-#pragma unroll 1
+// Decodes the 1024 values of wave tile wt into v[step][k] (lane l of step s holds group 64 s + l;
+// absent values zero); doff = data offset of the wave tile on entry, of the next one on return.
+template <bool ZZ>
+__device__ __forceinline__ void decode_wavetile64(const u8* __restrict__ in, const u8* __restrict__ data, u64& doff, u32 wt,
+                                                  u32 count, int lane, u64 (&v)[4][4]) {
+#pragma unroll
   for (int step = 0; step < 4; ++step) {
     const u64 g = (u64)wt * kWtKeys + 64 * step + lane;
     const u64 first = 4 * g;
@@ -167,23 +267,110 @@ __global__ __launch_bounds__(kBlock) void k_decode64(const u8* __restrict__ in, 
     const u32 incl = wave_scan_incl(L, lane);
     const u8* p = data + doff + (incl - L);
     doff += wave_last(incl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[step][k] = 0;
     if (nv) {
       uint4 lo4 = ld_u128(p), hi4 = ld_u128(p + 16);
       const u32 d[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      u64 v[4];
       u32 o = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const u32 len = (u32)k < nv ? 1u << ((key >> (2 * k)) & 3u) : 0u;
-        v[k] = len ? bytes64_at(d, o, len) : 0ull;
+        u64 x = len ? bytes64_at(d, o, len) : 0ull;
+        if (ZZ && len) x = zz_dec64(x);
+        v[step][k] = x;
         o += len;
       }
-      if (nv == 4u) {
-        st_stream16<(NT & kNtStores) != 0>(out + first, make_uint4((u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32)));
-        st_stream16<(NT & kNtStores) != 0>(out + first + 2, make_uint4((u32)v[2], (u32)(v[2] >> 32), (u32)v[3], (u32)(v[3] >> 32)));
-      } else {
-        for (u32 k = 0; k < nv; ++k) out[first + k] = v[k];
+    }
+  }
+}
+// Differential decode, first pass: the sum (mod 2^64) of the values of each workgroup's four wave tiles.
+template <bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_value_sums64(const u8* __restrict__ in, u32 count, Dir dir,
+                                                         u64* __restrict__ wg_sum) {
+  __shared__ u64 s_tot[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u32 wt = blockIdx.x * kWaves + wave;
+  u64 tot = 0;
+  if (wt < n_wt) {
+    u64 doff = dir_offset(dir, wt, lane);
+    u64 v[4][4];
+    decode_wavetile64<ZZ>(in, in + keylen, doff, wt, count, lane, v);
+#pragma unroll
+    for (int step = 0; step < 4; ++step) tot += v[step][0] + v[step][1] + v[step][2] + v[step][3];
+    tot = wave_sum64(tot);
+  }
+  if (lane == 0) s_tot[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) wg_sum[blockIdx.x] = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+}
+// blk[b] = sum of x[4096 b .. 4096 b + 4095] (the block sums k_multi_offsets starts from).
+__global__ __launch_bounds__(1024) void k_block_sums64(const u64* __restrict__ x, u64 n, u64* __restrict__ blk) {
+  __shared__ u64 s_wave[16];
+  const u64 g0 = ((u64)blockIdx.x * 1024 + threadIdx.x) * 4;
+  u64 sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sum += g0 + k < n ? x[g0 + k] : 0ull;
+  const u64 w = wave_sum64(sum);
+  if (lane_id() == 0) s_wave[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+    for (int i = 0; i < 16; ++i) t += s_wave[i];
+    blk[blockIdx.x] = t;
+  }
+}
+// DELTA: wg_base[blockIdx.x] = sum of the values of all earlier workgroups (k_value_sums64, scanned);
+// the values become running sums seeded with prev.
+template <bool DELTA, bool ZZ, int NT = 0>
+__global__ __launch_bounds__(kBlock) void k_decode64(const u8* __restrict__ in, u64* __restrict__ out, u32 count,
+                                                     Dir dir, u64* __restrict__ consumed, u64 prev,
+                                                     const u64* __restrict__ wg_base) {
+  __shared__ u64 s_tot[kWaves];
+  const int lane = lane_id(), wave = wave_id();
+  const u64 keylen = ((u64)count + 3) >> 2;
+  const u32 n_wt = (u32)((keylen + kWtKeys - 1) / kWtKeys);
+  const u32 wt = blockIdx.x * kWaves + wave;
+  if (!DELTA && wt >= n_wt) return;
+  u64 v[4][4];
+  u64 doff = 0;
+  if (wt < n_wt) {
+    doff = dir_offset(dir, wt, lane);
+    decode_wavetile64<ZZ>(in, in + keylen, doff, wt, count, lane, v);
+  }
+  if (DELTA) {
+    u64 carry = 0;  // sum of the steps before, inside this wave tile
+    if (wt < n_wt) {
+#pragma unroll
+      for (int step = 0; step < 4; ++step) {
+        v[step][1] += v[step][0]; v[step][2] += v[step][1]; v[step][3] += v[step][2];
+        const u64 incl = wave_scan_incl64(v[step][3]);
+        const u64 before = carry + incl - v[step][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[step][k] += before;
+        carry += ((u64)wave_last((u32)(incl >> 32)) << 32) | wave_last((u32)incl);
       }
+    }
+    if (lane == 0) s_tot[wave] = carry;
+    __syncthreads();
+    if (wt >= n_wt) return;
+    u64 base = prev + wg_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += s_tot[w];
+#pragma unroll
+    for (int step = 0; step < 4; ++step)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[step][k] += base;
+  }
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const u64 first = 4 * ((u64)wt * kWtKeys + 64 * step + lane);
+    if (first + 4 <= count) {
+      st_stream16<(NT & kNtStores) != 0>(out + first, make_uint4((u32)v[step][0], (u32)(v[step][0] >> 32), (u32)v[step][1], (u32)(v[step][1] >> 32)));
+      st_stream16<(NT & kNtStores) != 0>(out + first + 2, make_uint4((u32)v[step][2], (u32)(v[step][2] >> 32), (u32)v[step][3], (u32)(v[step][3] >> 32)));
+    } else {
+      for (u32 k = 0; k < 4 && first + k < count; ++k) out[first + k] = v[step][k];
     }
   }
   if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff;

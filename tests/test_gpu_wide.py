@@ -69,3 +69,47 @@ def test_encode64_decode64_match_oracle(env, oracle, kind):
         assert bool((back[n:] == -1).all()), "wrote past the output"
         assert int(codec.validate(d_in, expect.size, n, variant=2).item()) == 1
         assert int(codec.validate(d_in, expect.size + 1, n, variant=2).item()) == 0
+
+
+def _transform64(v, flags, prev):
+    """What SVBGPU_DELTA / SVBGPU_ZIGZAG code for 64-bit values (include/streamvbyte_gpu.h), in numpy:
+    wrap-around difference to the previous value, then zigzag.  Like the rest of the 1248 variant this has
+    no counterpart in the reference (parity unpinned); the rule mirrors its 32-bit forms
+    (src/streamvbytedelta_encode.c:54-55, src/streamvbyte_zigzag.c:3-6 there)."""
+    x = v.copy()
+    if flags & 1:
+        before = np.concatenate([np.array([prev], dtype=np.uint64), v[:-1]]) if v.size else v
+        x = v - before   # uint64 arithmetic wraps
+    if flags & 2:
+        x = (x << np.uint64(1)) ^ (np.uint64(0) - (x >> np.uint64(63)))
+    return x
+
+
+@pytest.mark.parametrize("flags", [1, 2, 3])
+def test_encode64_decode64_flags(env, oracle, flags):
+    torch, svb, codec = env
+    rng = np.random.default_rng(640 + flags)
+    prev = 0xFEDCBA9876543210
+    for n in [1, 5, 64, 255, 1025, 4096 * 3 + 1, 65537, (1 << 21) + 11]:
+        for kind in ("sorted", "mix", "small"):
+            if kind == "sorted":   # ascending 64-bit postings with gaps of every width
+                v = np.cumsum(gen64("shift", rng, n) >> np.uint64(20), dtype=np.uint64)
+            else:
+                v = gen64(kind, rng, n)
+            with np.errstate(over="ignore"):
+                expect = oracle.encode64(_transform64(v, flags, np.uint64(prev)))
+            d_v = torch.from_numpy(v.view(np.int64)).cuda()
+            buf = torch.full(((n + 3) // 4 + 8 * n + 32,), 0xCD, dtype=torch.uint8, device="cuda:0")
+            out, size = codec.encode64(d_v, out=buf, flags=flags, prev=prev)
+            torch.cuda.synchronize()
+            codec.check()
+            assert int(size.item()) == expect.size, (flags, kind, n)
+            got = buf.cpu().numpy()
+            assert np.array_equal(got[: expect.size], expect), (flags, kind, n)
+            assert np.all(got[expect.size:] == 0xCD), "wrote outside the stream"
+            pad = np.zeros(expect.size + 32, dtype=np.uint8)
+            pad[: expect.size] = expect
+            dec, used = codec.decode64(torch.from_numpy(pad).cuda(), n, flags=flags, prev=prev)
+            torch.cuda.synchronize()
+            assert int(used.item()) == expect.size
+            assert np.array_equal(dec.cpu().numpy().view(np.uint64), v), (flags, kind, n)
