@@ -153,6 +153,19 @@ int svbgpu_set_option(const char *name, int value);
  * calls, and two calls that share a workspace must be ordered on one stream. */
 size_t svbgpu_workspace_bytes(uint32_t count);
 
+/* Optional, once per workspace (no counterpart in the reference, which needs no scratch): zeroes the
+ * workspace on `stream` and remembers its address.  Calls that chain tiles through look-back words
+ * (svbgpu_encode, svbgpu_quantize_encode, svbgpu_encode64, svbgpu_zigzag_delta_decode) and
+ * svbgpu_validate then skip the clearing launch they otherwise start with (4-5 us a call, 5 % of an
+ * encode of 2^26 values): every such call marks the words it writes with a tag of its own, so what
+ * earlier calls left behind reads as empty.  Rules: the workspace must not be written by anything
+ * else between calls; call svbgpu_workspace_release before freeing it (an address that comes back from
+ * the allocator with other contents must not still be remembered); after a call that ended in
+ * SVBGPU_ESCAN initialise again.  Calls recorded into a HIP graph keep the clearing launch (a replay
+ * would repeat the tag).  Without it everything works as before. */
+int svbgpu_workspace_init(void *d_workspace, size_t workspace_bytes, void *stream);
+void svbgpu_workspace_release(void *d_workspace);
+
 /* After a stream synchronisation: SVBGPU_OK, or SVBGPU_ESCAN if a kernel that
  * used this workspace gave up waiting on another workgroup (never observed in
  * a correct run; bounded so that a bug cannot hang the device). */

@@ -247,6 +247,21 @@ class DeviceCodec:
         self.ws = make(self.ws_bytes, dtype=torch.uint8, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
         self.res = make(8, dtype=torch.int64, device=self.device)
+        # a codec that keeps its workspace has it initialised once, so that its calls skip the clearing
+        # launch (svbgpu_workspace_init); a per-call codec (zero=False) leaves that to every call
+        self._registered = False
+        if zero:
+            with torch.cuda.device(self.device):
+                _check(self.lib.svbgpu_workspace_init(self.ws.data_ptr(), self.ws_bytes, self._stream()),
+                       "svbgpu_workspace_init")
+            self._registered = True
+
+    def __del__(self):
+        try:
+            if getattr(self, "_registered", False):
+                self.lib.svbgpu_workspace_release(self.ws.data_ptr())
+        except Exception:
+            pass
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream

@@ -38,6 +38,8 @@ SIGNATURES = {
     "svbgpu_device_ok": (C.c_int, []),
     "svbgpu_build_has": (C.c_int, [C.c_char_p]),
     "svbgpu_workspace_bytes": (C.c_size_t, [C.c_uint32]),
+    "svbgpu_workspace_init": (C.c_int, [vp, C.c_size_t, vp]),
+    "svbgpu_workspace_release": (None, [vp]),
     "svbgpu_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "svbgpu_check_status": (C.c_int, [vp, vp]),
     "svbgpu_decode": (C.c_int, [C.c_int, C.c_uint, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, vp]),

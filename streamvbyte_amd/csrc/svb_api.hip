@@ -123,6 +123,7 @@ struct Options {
   int nt_threshold_mib;  // a call's loads / stores are non-temporal when it reads / writes at least this many MiB
                          // (-1: never, 0: always)
   int nt_force;          // -1: by size; 0..3: this policy whatever the size (bit 0 loads, bit 1 stores)
+  unsigned lb_tag2 = 0;  // not a knob: the look-back tag of the running call (LbWords::tag2), set by prepare_lookback
 };
 std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
     o_encode_qw{4}, o_encode_pipeline{1}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
@@ -186,6 +187,15 @@ inline int nt_policy_encode(const Options& o, int v, unsigned long long count) {
 }
 
 inline WsHeader* ws_hdr(void* ws) { return reinterpret_cast<WsHeader*>(ws); }
+// The header as a call with look-back tag `tag2` gets it: 8 bytes up for odd tags, whose tickets are
+// WsHeader::ticket1 (draw_ticket).  Only for kernels that reach the header through draw_ticket, the
+// look-back functions and nothing else.
+inline WsHeader* ws_hdr_slot(void* ws, unsigned tag2) {
+  return reinterpret_cast<WsHeader*>(reinterpret_cast<char*>(ws) + ((tag2 >> 3) & 1u) * 8);
+}
+inline LbWords lb_words(void* ws, const WsLayout& L, unsigned tag2) {
+  return LbWords{reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + L.off_status), (u32)((L.off_lb_group - L.off_status) / 8), tag2};
+}
 template <class T>
 inline T* ws_at(void* ws, size_t off) {
   return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off);
@@ -198,6 +208,34 @@ int fill_u32(void* ptr, uint32_t value, size_t bytes, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_u32, dim3(grid ? grid : 1), dim3(kBlock), 0, st, static_cast<u32*>(ptr), value, (u64)n);
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
+}
+
+// Workspaces whose look-back words were zeroed once by svbgpu_workspace_init: calls on them skip the
+// clearing launch and mark the words they write with a tag of their own, counted here per workspace.
+struct WsReg { u32 tag = 0; };
+std::mutex g_ws_mu;
+std::vector<std::pair<void*, WsReg>> g_ws_reg;  // a handful of entries: a linear search beats a hash
+WsReg* ws_find(void* ws) {
+  for (auto& e : g_ws_reg)
+    if (e.first == ws) return &e.second;
+  return nullptr;
+}
+bool ws_registered(void* ws) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  return ws_find(ws) != nullptr;
+}
+// The tag (shifted into place, LbWords::tag2) of a call that may skip the clearing launch, or 0: the
+// workspace is not initialised, the stream is being captured into a graph (a replay would reuse the
+// tag, so captured calls clear), or the tags have run out (this call clears and the count restarts).
+u32 next_lookback_tag(void* ws, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  WsReg* r = ws_find(ws);
+  if (!r) return 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (cs != hipStreamCaptureStatusNone) return 0;
+  if (++r->tag >= kLbTags) { r->tag = 0; return 0; }
+  return r->tag << 3;
 }
 
 int check_ws(uint32_t count, void* ws, size_t ws_bytes) {
@@ -240,6 +278,21 @@ int build_directory(int variant, const uint8_t* d_in, uint32_t count, void* ws, 
   HIP_TRY(hipGetLastError());
   return clear_lb ? arm_lookback_stress(ws, st) : SVBGPU_OK;
 }
+// What a look-back call does before its kernels: nothing but picking a tag on an initialised
+// workspace, else the clearing launch.
+int prepare_lookback(uint32_t count, void* ws, hipStream_t st, unsigned* tag2) {
+  *tag2 = next_lookback_tag(ws, st);
+  if (*tag2) return arm_lookback_stress(ws, st);
+  return clear_lookback(count, ws, st);
+}
+// ... and after them.  A call that cleared (tag 0) on an INITIALISED workspace -- recorded into a graph,
+// or the one call in 2^27 on which the tags ran out -- leaves its ticket counter used; a graph replay
+// happens without this code knowing, so such a call ends with a launch that puts both counters back
+// to zero, which is what the next tagged call counts on.
+int finish_lookback(void* ws, hipStream_t st, unsigned tag2) {
+  if (tag2 || !ws_registered(ws)) return SVBGPU_OK;
+  return fill_u32(&ws_hdr(ws)->ticket, 0u, 12, st);
+}
 inline Dir ws_dir(void* ws, const WsLayout& L) {
   return Dir{ws_at<u32>(ws, L.off_mega_sum), ws_at<u32>(ws, L.off_wt_rel), L.wt_per_mega};
 }
@@ -265,7 +318,7 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
   // over-allocated it and asked for them
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 64ull * (L.n_wt / 16 + 2) ? ws_at<u64>(ws, L.total) : nullptr;
   if (stamps && V == V1234 && !ZZ && o.scan_waves >= 8) {  // diagnostic instantiations with the stamps compiled in
-    const LbWords lbw{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+    const LbWords lbw = lb_words(ws, L, 0u);
     if (o.scan_waves == 16)
       hipLaunchKernelGGL((k_delta_decode<V1234, false, 16, 3, true>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024), 0, st,
                          d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws), lbw, d_consumed, stamps);
@@ -276,18 +329,18 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16, NTV>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024),
                                          0, st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
-                                         LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
+                                         lb_words(ws, L, 0u),
                                          d_consumed, (u64*)nullptr))
   else if (o.scan_waves >= 8)  // 8 waves per workgroup: 32 wave tiles per look-back tile
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 8, NTV>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0,
                                          st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
-                                         LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)},
+                                         lb_words(ws, L, 0u),
                                          d_consumed, (u64*)nullptr))
   else
   hipLaunchKernelGGL((k_delta_decode<V, ZZ>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in,
                      d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),
-                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed, (u64*)nullptr);
+                     lb_words(ws, L, 0u), d_consumed, (u64*)nullptr);
 }
 
 template <int V, bool ZZ>
@@ -365,8 +418,8 @@ void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, ui
   constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
   const unsigned full_tiles = (unsigned)(count / kTileInts);
   const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
-  WsHeader* h = ws_hdr(ws);
-  const LbWords status{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+  WsHeader* h = ws_hdr_slot(ws, o.lb_tag2);
+  const LbWords status = lb_words(ws, L, o.lb_tag2);
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
@@ -391,8 +444,8 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
   constexpr unsigned long long kTileInts = (unsigned long long)NW * QW * kWtInts;
   const unsigned full_tiles = (unsigned)(count / kTileInts);
   const bool ragged = (unsigned long long)full_tiles * kTileInts < count;
-  WsHeader* h = ws_hdr(ws);
-  const LbWords status{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+  WsHeader* h = ws_hdr_slot(ws, o.lb_tag2);
+  const LbWords status = lb_words(ws, L, o.lb_tag2);
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2) ? ws_at<u64>(ws, L.total) : nullptr;
   // the ticket a phase early pays for 0124 (short store phases), not for 1234
@@ -474,6 +527,27 @@ int svbgpu_build_has(const char* feature) {
   if (!std::strcmp(feature, "lookback_stress")) return 1;
 #endif
   return 0;
+}
+
+int svbgpu_workspace_init(void* ws, size_t ws_bytes, void* stream) {
+  if (!ws || ((uintptr_t)ws & 255u) || ws_bytes < sizeof(WsHeader) || (ws_bytes & 3u)) return SVBGPU_EWORKSPACE;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const int rc = fill_u32(ws, 0u, ws_bytes, S(stream));
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (WsReg* r = ws_find(ws)) r->tag = 0;
+  else g_ws_reg.emplace_back(ws, WsReg{});
+  return SVBGPU_OK;
+}
+
+void svbgpu_workspace_release(void* ws) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (size_t i = 0; i < g_ws_reg.size(); ++i)
+    if (g_ws_reg[i].first == ws) {
+      g_ws_reg[i] = g_ws_reg.back();
+      g_ws_reg.pop_back();
+      return;
+    }
 }
 
 int svbgpu_set_option(const char* name, int value) {
@@ -645,11 +719,12 @@ int svbgpu_encode(int variant, unsigned flags, const uint32_t* d_in, uint32_t co
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  rc = clear_lookback(count, ws, S(stream));
+  Options o = options();
+  rc = prepare_lookback(count, ws, S(stream), &o.lb_tag2);
   if (rc) return rc;
-  DISPATCH_VDZ(launch_encode, variant, flags, options(), d_in, count, d_out, prev, ws, ws_bytes, d_written, S(stream));
+  DISPATCH_VDZ(launch_encode, variant, flags, o, d_in, count, d_out, prev, ws, ws_bytes, d_written, S(stream));
   HIP_TRY(hipGetLastError());
-  return SVBGPU_OK;
+  return finish_lookback(ws, S(stream), o.lb_tag2);
 }
 
 int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float scale, uint8_t* d_out,
@@ -663,12 +738,12 @@ int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  rc = clear_lookback(count, ws, S(stream));
+  Options o = options();
+  rc = prepare_lookback(count, ws, S(stream), &o.lb_tag2);
   if (rc) return rc;
   uint32_t bits;
   std::memcpy(&bits, &scale, 4);
   const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
-  const Options o = options();
   if (o.encode_pipeline) {
     if (variant == SVBGPU_1234) launch_encode_pipe<V1234, false, true, 2, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
     else launch_encode_pipe<V0124, false, true, 2, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
@@ -677,7 +752,7 @@ int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float
   else
     launch_encode_qw<V0124, false, true, 4, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   HIP_TRY(hipGetLastError());
-  return SVBGPU_OK;
+  return finish_lookback(ws, S(stream), o.lb_tag2);
 }
 
 int svbgpu_decode_dequantize(int variant, const uint8_t* d_in, float* d_out, uint32_t count, float scale,
@@ -739,7 +814,9 @@ int svbgpu_validate(int variant, const uint8_t* d_in, uint64_t in_length, uint32
   }
   if (!d_in) return SVBGPU_EINVAL;
   WsHeader* h = ws_hdr(ws);
-  { int rc0 = fill_u32(&h->accum, 0u, 8, S(stream)); if (rc0) return rc0; }
+  // the kernel leaves the accumulator at zero behind it; only a workspace that was never initialised
+  // may hold anything else
+  if (!ws_registered(ws)) { int rc0 = fill_u32(&h->accum, 0u, 8, S(stream)); if (rc0) return rc0; }
   // a workgroup of 1024 threads per CU at most, at least 16 KiB of keys (one load per thread) each
   const unsigned grid = stream_grid((keylen + 16383) / 16384, 1);
   if (variant == SVBGPU_1234)
@@ -788,7 +865,8 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   const uint32_t count = (uint32_t)n;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  rc = clear_lookback(count, ws, S(stream));
+  unsigned tag2 = 0;
+  rc = prepare_lookback(count, ws, S(stream), &tag2);
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
   const u32 n_tiles8 = (u32)((L.n_wt + 31) / 32);  // 8 waves of 4 wave tiles per workgroup
@@ -798,18 +876,18 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
     SVB_NT_SWITCH_03(nt_policy(options(), 4ull * count, 4ull * count), NTV,
                      hipLaunchKernelGGL((k_running_sum<true, 16, NTV>), dim3(stream_grid(n_tiles16, 1)), dim3(1024), 0,
                                         S(stream), d_in, reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev,
-                                        n_tiles16, ws_hdr(ws),
-                                        LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}))
+                                        n_tiles16, ws_hdr_slot(ws, tag2),
+                                        lb_words(ws, L, tag2)))
   else if (scan_waves == 8)
     hipLaunchKernelGGL((k_running_sum<true, 8>), dim3(stream_grid(n_tiles8, 2)), dim3(512), 0, S(stream), d_in,
-                       reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles8, ws_hdr(ws),
-                       LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
+                       reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles8, ws_hdr_slot(ws, tag2),
+                       lb_words(ws, L, tag2));
   else
   hipLaunchKernelGGL(k_running_sum<true>, dim3(stream_grid(L.n_tiles, 4)), dim3(kBlock), 0, S(stream), d_in,
-                     reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, (u32)L.n_tiles, ws_hdr(ws),
-                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)});
+                     reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, (u32)L.n_tiles, ws_hdr_slot(ws, tag2),
+                     lb_words(ws, L, tag2));
   HIP_TRY(hipGetLastError());
-  return SVBGPU_OK;
+  return finish_lookback(ws, S(stream), tag2);
 }
 
 extern "C++" {
@@ -832,7 +910,7 @@ void launch_intersect(const uint8_t* d_in, uint32_t count, uint32_t prev, const 
     hipLaunchKernelGGL(k_wave_bounds, dim3((n_waves + kBlock - 1) / kBlock), dim3(kBlock), 0, st, vsum, blk, n_waves,
                        d_sorted, n_sorted, bound);
   hipLaunchKernelGGL((k_delta_intersect<V>), dim3((unsigned)L.n_tiles), dim3(kBlock), 0, st, d_in, count, dir, vsum, blk, d_sorted, n_sorted, bound, d_out, d_n_out, (u32)L.n_tiles, ws_hdr(ws),
-                     LbWords{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)}, d_consumed);
+                     lb_words(ws, L, 0u), d_consumed);
 }
 }  // extern "C++"
 
@@ -872,24 +950,25 @@ int svbgpu_encode64(unsigned flags, const uint64_t* d_in, uint32_t count, uint8_
   if (!dev_info().ok) return SVBGPU_ENODEVICE;
   int rc = check_ws(count, ws, ws_bytes);
   if (rc) return rc;
-  rc = clear_lookback(count, ws, S(stream));
+  unsigned tag2 = 0;
+  rc = prepare_lookback(count, ws, S(stream), &tag2);
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
   constexpr int NW = 8;  // wave tiles per look-back tile
   const unsigned n_tiles = (unsigned)((L.n_wt + NW - 1) / NW);
   const unsigned grid = stream_grid(n_tiles, 2);
-  const LbWords lbw{ws_at<u64>(ws, L.off_status), ws_at<u64>(ws, L.off_lb_group)};
+  const LbWords lbw = lb_words(ws, L, tag2);
   const Options o = options();
   const bool d = flags & SVBGPU_DELTA, z = flags & SVBGPU_ZIGZAG;
 #define SVB_ENC64(D, Z)                                                                                              \
   SVB_NT_SWITCH_013(nt_policy(o, 8ull * count, (count + 3ull) / 4 + count), NTV,                                     \
                     hipLaunchKernelGGL((k_encode64_lb<D, Z, NW, NTV>), dim3(grid), dim3(NW * 64), 0, S(stream), d_in, \
-                                       count, n_tiles, d_out, (u64)prev, ws_hdr(ws), lbw, d_written))
+                                       count, n_tiles, d_out, (u64)prev, ws_hdr_slot(ws, tag2), lbw, d_written))
   if (d) { if (z) SVB_ENC64(true, true) else SVB_ENC64(true, false) }
   else   { if (z) SVB_ENC64(false, true) else SVB_ENC64(false, false) }
 #undef SVB_ENC64
   HIP_TRY(hipGetLastError());
-  return SVBGPU_OK;
+  return finish_lookback(ws, S(stream), tag2);
 }
 
 int svbgpu_decode64(unsigned flags, const uint8_t* d_in, uint64_t* d_out, uint32_t count, uint64_t prev, void* ws,

@@ -75,7 +75,12 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
   const u64 t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0;  // diagnostic build only: 100 MHz wall clock
-  if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(&hdr->ticket, 1u);
+    // a workgroup per tile, a ticket each: the last one drawn leaves the counter as the next call expects it
+    if (t == gridDim.x - 1u) __hip_atomic_store(&hdr->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
   __syncthreads();
   const u32 tile = s_tile;
   // stamps of a tile: workgroup start, ticket in hand, keys and offsets in, decoded, prefix known, stored
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restric
   __syncthreads();
   const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
   if (tile >= n_tiles) break;
+  if (tile == 0u && threadIdx.x == 0) reset_other_ticket(hdr);
   const u64 wave_first = ((u64)tile * (NW * 4) + (u64)wave * 4) * kWtInts;
   uint4 v[4][4];
   const bool whole = wave_first + 4u * kWtInts <= count;  // wave-uniform: all 4096 values of this wave exist

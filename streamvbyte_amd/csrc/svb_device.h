@@ -272,8 +272,11 @@ __device__ __forceinline__ u32 zz_dec(u32 v) { return (v >> 1) ^ (0u - (v & 1u))
 struct WsHeader {
   u32 error;        // set non-zero when a bounded spin gave up
   u32 ticket;       // dynamic tile counter of the look-back kernels
+  u32 unused;       // (where `error` would be for a kernel handed the header 8 bytes up, see ticket1)
+  u32 ticket1;      // a second tile counter: calls on an initialised workspace alternate between the two,
+                    // each zeroing the one the next call will use (draw_ticket), so none needs a clearing
+                    // launch; such a call gets the header pointer 8 bytes up when its turn is ticket1
   u64 accum;        // reduction scratch (validate)
-  u64 reserved;
   u32 pad[58];
 };
 static_assert(sizeof(WsHeader) == 256, "header is one 256-byte block");

@@ -455,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
       s_prefix = excl;
       const u64 last_tile = keylen ? (keylen - 1) / ((u64)NW * QW * kWtKeys) : 0;
       if (tile == last_tile && written) *written = keylen + excl + tile_tot;
+      if (tile == 0u || !FULL) reset_other_ticket(hdr);  // once per call: the full tiles' kernel, and the ragged tile's
     }
   }
   __syncthreads();
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode_pipe(
     const u64 excl = lb2_resolve<kT>(lb, tile, tile_tot, lane, &hdr->error, &rounds, first);
     if (lane == 0) {
       s_prefix = excl;
+      if (tile == 0u) reset_other_ticket(hdr);
       if (tile == last_tile && written) *written = keylen + excl + tile_tot;
       if (stamps) {  // diagnostic build only: wall-clock stamps per tile, 100 MHz
         stamps[5 * (u64)tile + 2] = __builtin_amdgcn_s_memrealtime();

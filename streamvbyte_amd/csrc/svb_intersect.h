@@ -149,7 +149,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
   __shared__ u64 s_prefix;
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
-  if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(&hdr->ticket, 1u);
+    // a workgroup per tile, a ticket each: the last one drawn leaves the counter as the next call expects it
+    if (t == n_tiles - 1u) __hip_atomic_store(&hdr->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
   __syncthreads();
   const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
   WaveLds& S = s_lds[wave];

@@ -4,7 +4,9 @@
 // running tile has itself started and will publish without waiting on anything
 // later: the chain cannot deadlock whatever the dispatch order.  A status word is
 //     [63:62] 0 = nothing yet, 1 = AGGREGATE, 2 = inclusive PREFIX
-//     [61:0]  the value
+//     [61:35] the call's tag (see LbWords::tag2): a word whose tag is not the running call's reads as
+//             "nothing yet", so a workspace whose words were zero ONCE never needs clearing again
+//     [34:0]  the value (a stream of 64-bit values holds less than 2^35 data bytes)
 // written by ONE 8-byte agent-scope store and read by 8-byte agent-scope loads,
 // so flag and value travel together and no fence is needed (the value is the
 // whole payload).  Every spin is bounded; on give-up the error word of the
@@ -32,14 +34,49 @@
 
 namespace svb {
 
+// The header holds two ticket counters 8 bytes apart; a call works on the one its header pointer leads
+// to (WsHeader::ticket1), and the workgroup that handles its tile 0 zeroes the OTHER one: that is the
+// counter of the next call on this workspace, and nobody uses it now (the call before, which did, has
+// ended).  So a workspace that was zero once needs no clearing launch for its tickets.  (Kept out of
+// the ticket draw itself: the pipelined encoder has no scalar register to spare there.)
+__device__ __forceinline__ void reset_other_ticket(WsHeader* hdr) {
+  __hip_atomic_store(reinterpret_cast<u32*>(reinterpret_cast<uintptr_t>(&hdr->ticket) ^ 8u), 0u, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// The error word of the workspace whose header (or header + 8, see draw_ticket) `p` points into.
+__device__ __forceinline__ u32* ws_error_word(u32* p) {
+  return reinterpret_cast<u32*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)255);
+}
 constexpr u64 kLbAgg = 1ull << 62;
 constexpr u64 kLbPfx = 2ull << 62;
-constexpr u64 kLbVal = (1ull << 62) - 1;
+constexpr u64 kLbVal = (1ull << 35) - 1;
+#ifdef SVB_LB_STRESS
+constexpr u32 kLbTags = 1u << 4;   // stress build: the tags run out every 16 calls, so that tests see the wrap
+#else
+constexpr u32 kLbTags = 1u << 27;  // tags 1 .. kLbTags - 1
+#endif
 constexpr u32 kLbSpinLimit = 1u << 20;  // polls before giving up
 
 struct LbWords {
-  u64* tile;   // one word per tile: kLbAgg | value
-  u64* group;  // one word per 16 tiles: kLbAgg | aggregate, later kLbPfx | inclusive prefix
+  u64* tile;   // one word per tile: kLbAgg | tag | value
+  // one word per 16 tiles: kLbAgg | tag | aggregate, later kLbPfx | tag | inclusive prefix.  Kept as a
+  // distance from `tile` in words: one scalar register instead of two in kernels that have none to spare.
+  u32 group_off;
+  __device__ __forceinline__ u64* group_words() const { return tile + group_off; }
+  // The running call's tag, shifted to its place in the high dword of a word (bits 29..3 there).  0 for
+  // calls that clear the words first; 1 .. 2^27 - 1, counted per workspace by the host, for calls on
+  // an initialised workspace (svbgpu_workspace_init), which skip the clearing launch.
+  u32 tag2 = 0;
+  // flag of a word as this call sees it: 0 unless the word carries this call's tag
+  __device__ __forceinline__ u32 flag(u64 w) const {
+    const u32 hi = (u32)(w >> 32);
+    return ((hi ^ tag2) & 0x3FFFFFF8u) ? 0u : hi >> 30;
+  }
+  // value: a byte count below 2^35, or a sum that its users take modulo 2^32 (running sums of values may
+  // exceed the field: only the low bits are kept)
+  __device__ __forceinline__ u64 word(u64 flag_bits, u64 value) const {
+    return flag_bits | ((u64)tag2 << 32) | (value & ((1ull << 35) - 1));
+  }
 };
 // kT = tile words polled per lane: the window of tiles read one by one covers
 // the tile's own group and the 4 kT - 1 groups before it.
@@ -61,7 +98,7 @@ struct LbWords {
 constexpr int kLbStressWord = 32;
 __device__ __forceinline__ void lb_stress_delay(const u32* err, u32 tile, u32 salt) {
 #ifdef SVB_LB_STRESS
-  if (!err || !err[kLbStressWord]) return;  // wave-uniform
+  if (!err || !ws_error_word(const_cast<u32*>(err))[kLbStressWord]) return;  // wave-uniform
   const u32 h = (tile * 2654435761u + salt * 40503u) >> 13;
   if (h & 3u) return;
   const int naps = 2 + (int)((h >> 2) & 7u);  // about 8 .. 35 us
@@ -70,7 +107,7 @@ __device__ __forceinline__ void lb_stress_delay(const u32* err, u32 tile, u32 sa
 }
 __device__ __forceinline__ void lb2_publish(const LbWords& L, u32 tile, u64 my_agg, int lane, const u32* err = nullptr) {
   lb_stress_delay(err, tile, 0);
-  if (lane == 0) __hip_atomic_store(L.tile + tile, kLbAgg | my_agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(L.tile + tile, L.word(kLbAgg, my_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // What the first poll round of a look-back read (lb2_begin): words not yet
 // published are 0 and are polled again by lb2_resolve.
@@ -94,7 +131,7 @@ __device__ __forceinline__ LbState<kT> lb2_begin(const LbWords& L, u32 tile, int
     st.tw[i] = idx >= t0 ? __hip_atomic_load(L.tile + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   }
   const int gidx = (int)g0 - 1 - lane;
-  st.gw = gidx >= 0 ? __hip_atomic_load(L.group + gidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  st.gw = gidx >= 0 ? __hip_atomic_load(L.group_words() + gidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
   return st;
 }
 template <int kT = 2>
@@ -118,29 +155,29 @@ __device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_ag
 #pragma unroll
       for (int i = 0; i < kT; ++i) {
         const int idx = (int)tile - 1 - lane - 64 * i;
-        if (idx >= t0 && (tw[i] >> 62) == 0)
+        if (idx >= t0 && L.flag(tw[i]) == 0)
           tw[i] = __hip_atomic_load(L.tile + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (!group_done) {
       const int idx = gbase - lane;
-      if (idx < 0) gw = kLbPfx;  // before group 0: an empty prefix ends the chain
-      else if ((gw >> 62) == 0)
-        gw = __hip_atomic_load(L.group + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (idx < 0) gw = L.word(kLbPfx, 0);  // before group 0: an empty prefix ends the chain
+      else if (L.flag(gw) == 0)
+        gw = __hip_atomic_load(L.group_words() + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (leader && !agg_out && !__ballot(lane < 15 && (tw[0] >> 62) == 0)) {
+    if (leader && !agg_out && !__ballot(lane < 15 && L.flag(tw[0]) == 0)) {
       // the group is complete: let later groups count it
       agg_out = true;
       const u64 gagg = wave_sum64(lane < 15 ? (tw[0] & kLbVal) : 0ull) + my_agg;
       lb_stress_delay(err, tile, 1);
       if (lane == 0)
-        __hip_atomic_store(L.group + k, (k ? kLbAgg : kLbPfx) | gagg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(L.group_words() + k, L.word(k ? kLbAgg : kLbPfx, gagg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!tile_done) {
       bool missing = false;
 #pragma unroll
       for (int i = 0; i < kT; ++i)
-        missing |= ((int)tile - 1 - lane - 64 * i >= t0) && (tw[i] >> 62) == 0;
+        missing |= ((int)tile - 1 - lane - 64 * i >= t0) && L.flag(tw[i]) == 0;
       if (!__ballot(missing)) {
         tile_done = true;
         tile_round = rounds;
@@ -150,7 +187,7 @@ __device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_ag
       }
     }
     if (!group_done) {
-      const u32 flag = (u32)(gw >> 62);
+      const u32 flag = L.flag(gw);
       const u64 pfx = __ballot(flag == 2u);
       const u64 inv = __ballot(flag == 0u);
       const int first = pfx ? (int)__builtin_ctzll(pfx) : 64;       // nearest group prefix
@@ -171,14 +208,14 @@ __device__ __forceinline__ u64 lb2_resolve(const LbWords& L, u32 tile, u64 my_ag
     if (leader) __builtin_amdgcn_s_sleep(4);
     else __builtin_amdgcn_s_sleep(40);
     if (++spins > kLbSpinLimit) {
-      if (lane == 0) atomicOr(err, 1u);
+      if (lane == 0) atomicOr(ws_error_word(err), 1u);
       break;
     }
   }
   const u64 prefix = wave_sum64(mine);
   if (leader && k) lb_stress_delay(err, tile, 2);
   if (leader && k && lane == 0)
-    __hip_atomic_store(L.group + k, kLbPfx | (prefix + my_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(L.group_words() + k, L.word(kLbPfx, prefix + my_agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (rounds_out) *rounds_out = rounds | (tile_round << 8) | (group_round << 16);
   return prefix;
 }

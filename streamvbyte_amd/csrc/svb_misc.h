@@ -152,8 +152,10 @@ __global__ __launch_bounds__(NT) void k_validate_sum(const u8* __restrict__ in, 
     // one atomic per workgroup carries its sum (low 48 bits; a stream holds < 2^35
     // data bytes) and counts it in (high 16 bits; the grid has < 2^16 workgroups)
     const u64 old = atomicAdd(reinterpret_cast<unsigned long long*>(accum), (unsigned long long)(tot | (1ull << 48)));
-    if ((old >> 48) == gridDim.x - 1)  // every other workgroup's sum is in
+    if ((old >> 48) == gridDim.x - 1) {  // every other workgroup's sum is in
       *ok = ((old & ((1ull << 48) - 1)) + tot) == in_length - keylen;
+      *accum = 0;  // nobody adds after the last: the next call finds the accumulator as it must be
+    }
   }
 }
 

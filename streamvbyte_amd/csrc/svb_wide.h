@@ -133,6 +133,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode64_lb(const u64* __restric
       const u64 excl = lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error);
       if (lane == 0) {
         s_prefix = excl;
+        if (tile == 0u) reset_other_ticket(hdr);
         if (tile == n_tiles - 1 && written) *written = keylen + excl + tile_tot;
       }
     }

@@ -70,6 +70,14 @@ def test_lookback_kernels_are_exact_under_delays(oracle, stressed, n):
             codec.check()
             assert int(used.item()) == expect.size
             assert np.array_equal(to_np(dec, np.uint32), v)
+    # the stress build has only 15 tags: twenty more calls on this (initialised) workspace wrap them
+    small = GENERATORS["perf_c"](rng, 70001)
+    want = oracle.encode(V1234, small)
+    stressed.svbgpu_set_option(b"encode_pipeline", 1)
+    for _ in range(20):
+        out, size = codec.encode(to_dev(torch, small))
+        assert int(size.item()) == want.size and np.array_equal(out[: want.size].cpu().numpy(), want)
+    codec.check()
     # running sum (zigzag_delta_decode) and its inverse
     z = codec.zigzag(d_v, "delta_decode", prev=-5)
     codec.check()

@@ -16,6 +16,7 @@ codec = svb.DeviceCodec(n, dev)
 need = codec.ws_bytes
 waves = int(sys.argv[3]) if len(sys.argv) > 3 else 16   # waves per workgroup: 16 or 8 (option scan_waves)
 tiles = (n // 1024 + 4 * waves - 1) // (4 * waves)
+codec.lib.svbgpu_workspace_release(codec.ws.data_ptr()); codec._registered = False  # the stamps need room behind a workspace of their own
 codec.ws = torch.zeros(need + 64 * (n // 1024 // 16 + 8), dtype=torch.uint8, device=dev)
 codec.ws_bytes = codec.ws.numel()
 if mode == "dense":

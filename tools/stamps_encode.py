@@ -13,6 +13,7 @@ n = 1 << log2n
 codec = svb.DeviceCodec(n, "cuda:0")
 # over-allocate the workspace so the stamps fit behind it
 need = codec.ws_bytes
+codec.lib.svbgpu_workspace_release(codec.ws.data_ptr()); codec._registered = False  # the stamps need room behind a workspace of their own
 codec.ws = torch.zeros(need + 64 * (n // 4096 + 8), dtype=torch.uint8, device="cuda:0")
 codec.ws_bytes = codec.ws.numel()
 values = gen_width_mix(torch, n, 1, "cuda:0")

@@ -12,6 +12,7 @@ tile_wt = int(sys.argv[2]) if len(sys.argv) > 2 else 16  # wave tiles per look-b
 n = 1 << log2n
 codec = svb.DeviceCodec(n, "cuda:0")
 need = codec.ws_bytes
+codec.lib.svbgpu_workspace_release(codec.ws.data_ptr()); codec._registered = False  # the stamps need room behind a workspace of their own
 codec.ws = torch.zeros(need + 64 * (n // 4096 + 8), dtype=torch.uint8, device="cuda:0")
 codec.ws_bytes = codec.ws.numel()
 mode = sys.argv[3] if len(sys.argv) > 3 else "mix"
