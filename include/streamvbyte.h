@@ -8,8 +8,8 @@
  *
  * Pointers may be host pointers or device pointers from hipMalloc.
  *   - Host pointers: calls of 65 536 values or more are staged through device
- *     memory and run on the GPU; smaller ones run on the calling thread (SSE4.1 /
- *     SSSE3 code inside the library, same bytes either way) because two PCIe
+ *     memory and run on the GPU; smaller ones run on the calling thread (AVX-512,
+ *     SSE4.1 / SSSE3 or scalar code inside the library, same bytes either way) because two PCIe
  *     crossings cost more than the work.  The threshold is the option
  *     "host_cpu_cutoff" of svbgpu_set_option (streamvbyte_gpu.h); 0 sends every
  *     call to the GPU.  Without a usable gfx950 device every call runs on the
@@ -22,6 +22,20 @@
  *     in memory, so a caller needs no synchronisation of its own on either side.
  *     Callers that want asynchronous calls on their own stream use
  *     streamvbyte_gpu.h.
+ *   - Threads: any thread may call any function at any time on buffers of its
+ *     own, as with the reference.  Calls that run on the calling thread are as
+ *     independent as the reference's.  Calls that go to the GPU take turns: by
+ *     default one host-pointer call at a time per device runs inside the library
+ *     (a mutex; option "host_serialize").  That is a precaution, not a known
+ *     necessity -- an abort seen once with eight threads in such calls was never
+ *     explained or seen again (profiles/r3_thread_stress.txt in the source tree
+ *     records the runs with the mutex off) -- and costs nothing measurable: such
+ *     calls are bound by the PCIe link they share anyway.
+ *   - What kind a pointer is, is asked of the HIP runtime per call (about 0.1 us
+ *     per pointer; never for memory on the caller's own stack, never in a process
+ *     without a device).  A program that only passes host memory can switch the
+ *     question off: SVB_HOST_POINTERS_ONLY=1 in the environment, or option
+ *     "host_pointers_only".
  *
  * Stream layout for `length` values: (length+3)/4 control bytes, then the data
  * bytes.  `length` itself is not stored.

@@ -1332,7 +1332,7 @@ uint64_t fetch_total_data(Ctx* c, uint32_t count) {
   return total;
 }
 void check_scan(Ctx* c) {
-  if (o_debug.load(std::memory_order_relaxed) & 64u) {
+  if (o_debug.load(std::memory_order_relaxed) & 128u) {
     // diagnostic only: the status read as it was before the concurrency fix, an asynchronous copy into
     // a variable on the calling thread's stack (tools/stress_threads.py ... stack)
     u32 err = 0;

@@ -54,19 +54,23 @@ __device__ __forceinline__ uint4 ld_u128(const u8* p) {
 // of the call -- short streams keep the default policy, their bytes are likely to be used again from
 // the cache by whatever runs next.
 constexpr int kNtLoads = 1, kNtStores = 2;
+// The pointers these take are value and stream addresses of the caller's: uint32 arrays are only
+// 4-byte aligned (batched calls start a stream's values anywhere in an array), so the vector type says
+// 4 and not 16 -- gfx950 executes a dwordx4 access at any dword address, but a type that promises
+// more than the pointer keeps would be undefined behaviour the compiler may build on.
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32x4_t u32x4_a4 __attribute__((aligned(4)));
 template <bool NT>
 __device__ __forceinline__ uint4 ld_stream16(const void* p) {
-  if (NT) {
-    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-  }
-  return *reinterpret_cast<const uint4*>(p);
+  const u32x4_a4* q = reinterpret_cast<const u32x4_a4*>(p);
+  const u32x4_t v = NT ? __builtin_nontemporal_load(q) : *q;
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 template <bool NT>
 __device__ __forceinline__ void st_stream16(void* p, const uint4& v) {
-  if (NT) __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
-  else *reinterpret_cast<uint4*>(p) = v;
+  u32x4_a4* q = reinterpret_cast<u32x4_a4*>(p);
+  if (NT) __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, q);
+  else *q = u32x4_t{v.x, v.y, v.z, v.w};
 }
 __device__ __forceinline__ u32 lds_u32(const u8* p) {
   u32 v;

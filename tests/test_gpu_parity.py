@@ -690,3 +690,33 @@ def test_device_api_from_concurrent_threads(torch_mod, oracle):
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+def test_value_arrays_at_dword_alignment_with_nontemporal_accesses(torch_mod, codec, oracle):
+    """The 16-byte stream accessors (ld_stream16 / st_stream16) get value pointers that are only 4-byte
+    aligned: input and output one value past a 16-byte boundary, every cache policy forced in turn."""
+    torch = torch_mod
+    from streamvbyte_amd import DELTA
+    n = (1 << 20) + 3
+    v = gen("width_mix", n, 41)
+    base_in = torch.zeros(n + 4, dtype=torch.int32, device="cuda:0")
+    base_out = torch.zeros(n + 4, dtype=torch.int32, device="cuda:0")
+    for shift in (1, 2, 3):
+        d_v, d_out = base_in[shift:shift + n], base_out[shift:shift + n]
+        assert d_v.data_ptr() % 16 == 4 * shift
+        d_v.copy_(to_dev(torch, v))
+        for nt in (3, 0):
+            codec.lib.svbgpu_set_option(b"nt_force", nt)
+            try:
+                for variant, flags, prev in ((V1234, 0, 0), (V0124, 0, 0), (V1234, DELTA, 9)):
+                    expect = oracle.encode(variant, v, bool(flags), prev)
+                    out, size = codec.encode(d_v, variant=variant, flags=flags, prev=prev)
+                    assert int(size.item()) == expect.size
+                    assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (shift, nt, variant, flags)
+                    base_out.fill_(-1)
+                    codec.decode(dev_stream(torch, expect), n, out=d_out, variant=variant, flags=flags, prev=prev)
+                    assert np.array_equal(to_np(d_out, np.uint32), v), (shift, nt, variant, flags)
+                    assert bool((base_out[:shift] == -1).all()) and bool((base_out[shift + n:] == -1).all())
+            finally:
+                codec.lib.svbgpu_set_option(b"nt_force", -1)
+    codec.check()

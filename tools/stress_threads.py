@@ -22,7 +22,7 @@ assert L.svbgpu_set_option(b"host_cpu_cutoff", 0) == 0     # every call to the G
 assert L.svbgpu_set_option(b"host_serialize", serialize) == 0
 assert L.svbgpu_set_option(b"host_stage_pageable", stage) == 0
 stack_status = len(sys.argv) > 6 and sys.argv[6] == "stack"  # look-back status copied into a stack variable (as before the fix)
-assert L.svbgpu_set_option(b"debug_ablate", 64 if stack_status else 0) == 0
+assert L.svbgpu_set_option(b"debug_ablate", 128 if stack_status else 0) == 0
 print(f"threads {T} iters {ITERS} what {what} serialize {serialize} stage_pageable {stage} stack_status {stack_status}", flush=True)
 errors = []
 
