@@ -91,3 +91,11 @@ def test_lookback_kernels_are_exact_under_delays(oracle, stressed, n):
     want = post[np.isin(post, probe)]
     assert int(nhits.item()) == want.size
     assert np.array_equal(to_np(hits[: want.size], np.uint32), want)
+    # 64-bit values: the single-pass 1248 encoder chains its tiles the same way
+    w = (rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+         >> (np.uint64(64) - (np.uint64(8) << rng.integers(0, 4, size=n).astype(np.uint64))))
+    want64 = oracle.encode64(w)
+    out, size = codec.encode64(torch.from_numpy(w.view(np.int64)).cuda())
+    codec.check()
+    assert int(size.item()) == want64.size
+    assert np.array_equal(out[: want64.size].cpu().numpy(), want64)
