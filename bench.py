@@ -504,30 +504,41 @@ def main():
             "Gvalues_per_s": round(n3 / ms_i / 1e6, 1),
             "parity": bool(k_hits == expect_hits.numel() and torch.equal(out[:k_hits], expect_hits))}
         del post, s3, sorted_b, expect_hits
-        # C3 mixed: 1-3 byte gaps, running sum wraps modulo 2^32, prev != 0
-        n3b = min(n, 1 << 26)
-        r31 = torch.randint(0, 1 << 31, (n3b,), generator=g, device=device, dtype=torch.int64)
-        sh = torch.randint(0, 32, (n3b,), generator=g, device=device, dtype=torch.int64)
-        gaps = (r31 >> sh) >> 8
-        post = (torch.cumsum(gaps, 0) + 0xDEADBEEF) & 0xFFFFFFFF
-        post = torch.where(post >= (1 << 31), post - (1 << 32), post).to(torch.int32)
-        del r31, sh, gaps
-        s3, z3 = codec.encode(post, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF)
-        d3b = (int(z3.item()) - (n3b + 3) // 4) / n3b
-        o3 = out[:n3b]
-        ms_e, _ = event_ms(torch, lambda: codec.encode(post, out=enc_out, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF), it)
-        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)   # the two-pass decoder, for comparison
-        ms_d2, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
-        codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
-        ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
-        codec.check()
-        extra["delta_mixed_gaps"] = {"n": n3b, "data_bytes_per_value": round(d3b, 4), "prev": "0xDEADBEEF",
-                                     "parity": bool(torch.equal(o3, post)),
-                                     "decode_two_pass_GBps": round(4.0 * n3b / ms_d2 / 1e6, 1),
-                                     "decode_GBps": round(4.0 * n3b / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n3b / ms_e / 1e6, 1),
-                                     "decode_roofline_frac": round((4.25 + d3b) * n3b / ms_d / 1e6 / HBM_PEAK_GBS, 4),
-                                     "encode_roofline_frac": round((4.25 + d3b) * n3b / ms_e / 1e6 / HBM_PEAK_GBS, 4)}
-        del post, s3
+        # C3 mixed: 1-3 byte gaps, running sum wraps modulo 2^32, prev != 0; at 2^26 values and at the workload's size
+        def mixed_gaps(n3b):
+            r31 = torch.randint(0, 1 << 31, (n3b,), generator=g, device=device, dtype=torch.int64)
+            sh = torch.randint(0, 32, (n3b,), generator=g, device=device, dtype=torch.int64)
+            gaps = (r31 >> sh) >> 8
+            del r31, sh
+            post = (torch.cumsum(gaps, 0) + 0xDEADBEEF) & 0xFFFFFFFF
+            del gaps
+            post = torch.where(post >= (1 << 31), post - (1 << 32), post).to(torch.int32)
+            s3, z3 = codec.encode(post, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF)
+            s3 = s3[: int(z3.item()) + 16].clone()
+            d3b = (int(z3.item()) - (n3b + 3) // 4) / n3b
+            o3 = out[:n3b]
+            enc = lambda: codec.encode(post, out=enc_out, variant=svb.V1234, flags=svb.DELTA, prev=0xDEADBEEF)
+            ms_e, _ = event_ms(torch, enc, it)
+            codec.lib.svbgpu_set_option(b"encode_pipeline", 2)         # the pipelined encoder for differential input too
+            ms_ep, _ = event_ms(torch, enc, it)
+            same = bool(torch.equal(enc_out[: s3.numel() - 16], s3[:-16]))
+            codec.lib.svbgpu_set_option(b"encode_pipeline", 1)
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", 0)   # the two-pass decoder, for comparison
+            ms_d2, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
+            codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
+            ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
+            codec.check()
+            frac = lambda ms: round((4.25 + d3b) * n3b / ms / 1e6 / HBM_PEAK_GBS, 4)
+            return {"n": n3b, "data_bytes_per_value": round(d3b, 4), "prev": "0xDEADBEEF",
+                    "parity": bool(torch.equal(o3, post)) and same,
+                    "decode_two_pass_GBps": round(4.0 * n3b / ms_d2 / 1e6, 1),
+                    "decode_GBps": round(4.0 * n3b / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n3b / ms_e / 1e6, 1),
+                    "encode_pipelined_GBps": round(4.0 * n3b / ms_ep / 1e6, 1),
+                    "decode_roofline_frac": frac(ms_d), "encode_roofline_frac": frac(ms_e),
+                    "encode_pipelined_roofline_frac": frac(ms_ep)}
+        extra["delta_mixed_gaps"] = mixed_gaps(min(n, 1 << 26))
+        if n > (1 << 26):
+            extra["delta_mixed_gaps_full_size"] = mixed_gaps(n)
         # 64-bit values (the 1248 variant; no reference counterpart): widths 1, 2, 4, 8 bytes equally likely
         n8 = min(n, 1 << 27)
         w8 = torch.randint(0, 4, (n8,), generator=g, device=device, dtype=torch.int64)

@@ -307,11 +307,25 @@ static inline size_t svbgpu_max_compressedbytes64(uint32_t count) {
  * sums; SVBGPU_ZIGZAG maps through (v << 1) ^ (0 - (v >> 63)) before coding and back after decoding;
  * both together code the zigzag of the difference.  The encoder is one pass over the values (tile
  * offsets by decoupled look-back, as for 32-bit values); the differential decoder reads the stream
- * twice (value sums per 4096 values first).  No batched form. */
+ * twice (value sums per 4096 values first). */
 int svbgpu_encode64(unsigned flags, const uint64_t *d_in, uint32_t count, uint8_t *d_out, uint64_t prev,
                     void *d_workspace, size_t workspace_bytes, uint64_t *d_written, void *stream);
 int svbgpu_decode64(unsigned flags, const uint8_t *d_in, uint64_t *d_out, uint32_t count, uint64_t prev,
                     void *d_workspace, size_t workspace_bytes, uint64_t *d_consumed, void *stream);
+/* Batched 64-bit calls: `nstreams` independent 1248 streams in one launch, arguments as for
+ * svbgpu_encode_batch / svbgpu_decode_batch below (offsets in elements resp. bytes, d_prev may be NULL,
+ * d_sizes[s] = bytes written / consumed; optional for decode).  For encode, d_byte_off[s] must leave
+ * svbgpu_max_compressedbytes64(d_counts[s]) - SVBGPU_PADDING64 bytes for stream s; for decode, the last
+ * stream of the buffer must be followed by SVBGPU_PADDING64 readable bytes (a stream inside the buffer is
+ * followed by its neighbour, which serves).  A wavefront per stream, a wave tile (1024 values) at a
+ * time: made for many streams of 10^3..10^5 values; streams of a few values leave most lanes idle.
+ * No counterpart in the reference. */
+int svbgpu_encode64_batch(unsigned flags, const uint64_t *d_values, const uint64_t *d_value_off, uint8_t *d_bytes,
+                          const uint64_t *d_byte_off, const uint32_t *d_counts, const uint64_t *d_prev,
+                          uint32_t nstreams, uint64_t *d_sizes, void *stream);
+int svbgpu_decode64_batch(unsigned flags, const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t *d_values,
+                          const uint64_t *d_value_off, const uint32_t *d_counts, const uint64_t *d_prev,
+                          uint32_t nstreams, uint64_t *d_sizes, void *stream);
 
 /*
  * Batched entry points: `nstreams` independent streams in one launch (posting

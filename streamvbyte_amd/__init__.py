@@ -434,6 +434,31 @@ class DeviceCodec:
                                                 sizes.data_ptr(), self._stream()), "svbgpu_decode_batch")
         return sizes
 
+    def encode64_batch(self, values, value_off, byte_buf, byte_off, counts, prevs=None, flags=0, sizes=None):
+        """svbgpu_encode64_batch: int64 `values`, one 1248 stream per entry of `counts`; prevs int64 or None."""
+        torch = self.torch
+        ns = counts.numel()
+        if sizes is None:
+            sizes = torch.empty(ns, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_encode64_batch(flags, values.data_ptr(), value_off.data_ptr(), byte_buf.data_ptr(),
+                                                  byte_off.data_ptr(), counts.data_ptr(),
+                                                  prevs.data_ptr() if prevs is not None else None, ns,
+                                                  sizes.data_ptr(), self._stream()), "svbgpu_encode64_batch")
+        return sizes
+
+    def decode64_batch(self, byte_buf, byte_off, values, value_off, counts, prevs=None, flags=0, sizes=None):
+        torch = self.torch
+        ns = counts.numel()
+        if sizes is None:
+            sizes = torch.empty(ns, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_decode64_batch(flags, byte_buf.data_ptr(), byte_off.data_ptr(), values.data_ptr(),
+                                                  value_off.data_ptr(), counts.data_ptr(),
+                                                  prevs.data_ptr() if prevs is not None else None, ns,
+                                                  sizes.data_ptr(), self._stream()), "svbgpu_decode64_batch")
+        return sizes
+
     def validate_batch(self, byte_buf, byte_off, lengths, counts, variant=V1234):
         """Per-stream streamvbyte_validate_stream: int32 tensor of 1 / 0."""
         torch = self.torch

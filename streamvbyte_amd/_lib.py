@@ -60,6 +60,8 @@ SIGNATURES = {
     "svbgpu_zigzag_delta_decode": (C.c_int, [vp, vp, C.c_size_t, C.c_int32, vp, C.c_size_t, vp]),
     "svbgpu_encode64": (C.c_int, [C.c_uint, vp, C.c_uint32, vp, C.c_uint64, vp, C.c_size_t, vp, vp]),
     "svbgpu_decode64": (C.c_int, [C.c_uint, vp, vp, C.c_uint32, C.c_uint64, vp, C.c_size_t, vp, vp]),
+    "svbgpu_encode64_batch": (C.c_int, [C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    "svbgpu_decode64_batch": (C.c_int, [C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbgpu_encode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbgpu_decode_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     # include/streamvbyte_multi.h

@@ -1059,6 +1059,44 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t* d_bytes, con
   return SVBGPU_OK;
 }
 
+int svbgpu_encode64_batch(unsigned flags, const uint64_t* d_values, const uint64_t* d_value_off, uint8_t* d_bytes,
+                          const uint64_t* d_byte_off, const uint32_t* d_counts, const uint64_t* d_prev,
+                          uint32_t nstreams, uint64_t* d_sizes, void* stream) {
+  if (bad_flags(flags)) return SVBGPU_EINVAL;
+  if (nstreams == 0) return SVBGPU_OK;
+  if (!d_values || !d_value_off || !d_bytes || !d_byte_off || !d_counts || !d_sizes) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = (nstreams + kBatch64Waves - 1) / kBatch64Waves;
+  const bool d = flags & SVBGPU_DELTA, z = flags & SVBGPU_ZIGZAG;
+#define SVB_ENC64B(D, Z)                                                                                          \
+  hipLaunchKernelGGL((k_encode64_batch<D, Z>), dim3(grid), dim3(64 * kBatch64Waves), 0, S(stream), d_values, d_value_off, d_bytes, \
+                     d_byte_off, d_counts, d_prev, nstreams, d_sizes)
+  if (d) { if (z) SVB_ENC64B(true, true); else SVB_ENC64B(true, false); }
+  else   { if (z) SVB_ENC64B(false, true); else SVB_ENC64B(false, false); }
+#undef SVB_ENC64B
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_decode64_batch(unsigned flags, const uint8_t* d_bytes, const uint64_t* d_byte_off, uint64_t* d_values,
+                          const uint64_t* d_value_off, const uint32_t* d_counts, const uint64_t* d_prev,
+                          uint32_t nstreams, uint64_t* d_sizes, void* stream) {
+  if (bad_flags(flags)) return SVBGPU_EINVAL;
+  if (nstreams == 0) return SVBGPU_OK;
+  if (!d_bytes || !d_byte_off || !d_values || !d_value_off || !d_counts) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = (nstreams + kBatch64Waves - 1) / kBatch64Waves;
+  const bool d = flags & SVBGPU_DELTA, z = flags & SVBGPU_ZIGZAG;
+#define SVB_DEC64B(D, Z)                                                                                          \
+  hipLaunchKernelGGL((k_decode64_batch<D, Z>), dim3(grid), dim3(64 * kBatch64Waves), 0, S(stream), d_bytes, d_byte_off, d_values, \
+                     d_value_off, d_counts, d_prev, nstreams, d_sizes)
+  if (d) { if (z) SVB_DEC64B(true, true); else SVB_DEC64B(true, false); }
+  else   { if (z) SVB_DEC64B(false, true); else SVB_DEC64B(false, false); }
+#undef SVB_DEC64B
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
 }  // extern "C"
 
 // =============================================================================

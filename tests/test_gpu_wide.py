@@ -113,3 +113,65 @@ def test_encode64_decode64_flags(env, oracle, flags):
             torch.cuda.synchronize()
             assert int(used.item()) == expect.size
             assert np.array_equal(dec.cpu().numpy().view(np.uint64), v), (flags, kind, n)
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_encode64_decode64_batch(env, oracle, flags):
+    """svbgpu_encode64_batch / svbgpu_decode64_batch: every stream's bytes equal the oracle's for that stream
+    alone, nothing is written between the streams, the decoder gives the values back; stream borders at every
+    alignment, counts from 0 over tile edges to several wave tiles."""
+    torch, svb, codec = env
+    rng = np.random.default_rng(6400 + flags)
+    counts = np.array([0, 1, 2, 3, 4, 5, 7, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2049, 4099, 0, 9, 5000, 1, 3071],
+                      dtype=np.uint32)
+    ns = counts.size
+    kinds = ["mix", "shift", "small", "max", "zeros", "sorted"]
+    vals, prevs = [], rng.integers(0, 1 << 63, size=ns, dtype=np.uint64) * np.uint64(3)
+    for s, n in enumerate(counts):
+        kind = kinds[s % len(kinds)]
+        if kind == "sorted":
+            vals.append(np.cumsum(gen64("shift", rng, int(n)) >> np.uint64(20), dtype=np.uint64))
+        else:
+            vals.append(gen64(kind, rng, int(n)))
+    value_off = np.zeros(ns, dtype=np.uint64)
+    value_off[1:] = np.cumsum(counts[:-1])
+    # places: worst case of each stream plus a gap of 0..5 bytes, so that streams start at every alignment
+    worst = (counts.astype(np.uint64) + 3) // 4 + 8 * counts.astype(np.uint64)
+    gap = rng.integers(0, 6, size=ns).astype(np.uint64)
+    byte_off = np.zeros(ns, dtype=np.uint64)
+    byte_off[1:] = np.cumsum(worst[:-1] + gap[:-1])
+    total = int(byte_off[-1] + worst[-1]) + 32
+    allv = np.concatenate(vals) if ns else np.zeros(0, dtype=np.uint64)
+    d_vals = torch.from_numpy(allv.view(np.int64)).cuda()
+    d_voff = torch.from_numpy(value_off.view(np.int64)).cuda()
+    d_boff = torch.from_numpy(byte_off.view(np.int64)).cuda()
+    d_cnt = torch.from_numpy(counts.view(np.int32)).cuda()
+    d_prev = torch.from_numpy(prevs.view(np.int64)).cuda()
+    buf = torch.full((total,), 0xEE, dtype=torch.uint8, device="cuda:0")
+    sizes = codec.encode64_batch(d_vals, d_voff, buf, d_boff, d_cnt, prevs=d_prev, flags=flags)
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    sz = sizes.cpu().numpy()
+    covered = np.zeros(total, dtype=bool)
+    packed = []
+    for s in range(ns):
+        with np.errstate(over="ignore"):
+            expect = oracle.encode64(_transform64(vals[s], flags, prevs[s]))
+        assert int(sz[s]) == expect.size, (flags, s, counts[s])
+        o = int(byte_off[s])
+        assert np.array_equal(got[o: o + expect.size], expect), (flags, s, counts[s])
+        covered[o: o + expect.size] = True
+        packed.append(expect)
+    assert np.all(got[~covered] == 0xEE), "wrote outside the streams"
+    # decode from a packed buffer: streams back to back (each followed by its neighbour), 32 bytes behind the last
+    poff = np.zeros(ns, dtype=np.uint64)
+    poff[1:] = np.cumsum([p.size for p in packed[:-1]])
+    pk = np.concatenate(packed + [np.zeros(32, dtype=np.uint8)])
+    d_pk = torch.from_numpy(pk).cuda()
+    d_poff = torch.from_numpy(poff.view(np.int64)).cuda()
+    back = torch.full((allv.size + 4,), -1, dtype=torch.int64, device="cuda:0")
+    used = codec.decode64_batch(d_pk, d_poff, back, d_voff, d_cnt, prevs=d_prev, flags=flags)
+    torch.cuda.synchronize()
+    assert np.array_equal(used.cpu().numpy(), np.array([p.size for p in packed]))
+    assert np.array_equal(back[: allv.size].cpu().numpy().view(np.uint64), allv), flags
+    assert bool((back[allv.size:] == -1).all()), "wrote past the output"

@@ -148,6 +148,24 @@ if want("wide"):
     e8 = torch.empty((n8 + 3) // 4 + 8 * n8 + 32, dtype=torch.uint8, device=dev)
     ops["encode64"] = (lambda: codec.encode64(v8, out=e8), (8.25 + d8) * n8)
     ops["decode64"] = (lambda: codec.decode64(s8, n8, out=o8), (8.25 + d8) * n8)
+if want("wide_batch"):
+    # 2^19 lists of 64-bit postings (the 32-bit posting lists' lengths and gaps, widened), delta coded
+    nl8 = 1 << 19
+    c8, vo8, va8 = gen_posting_lists(torch, list_lengths(nl8, 20241218), 1234, dev)
+    va8 = (va8.to(torch.int64) & 0xFFFFFFFF) + (1 << 40)
+    tot8 = int(vo8[-1].item())
+    cap8 = (c8.to(torch.int64) + 3) // 4 + 8 * c8.to(torch.int64)
+    bo8 = torch.zeros(nl8 + 1, dtype=torch.int64, device=dev)
+    bo8[1:] = torch.cumsum(cap8, 0)
+    bb8 = torch.empty(int(bo8[-1].item()) + 32, dtype=torch.uint8, device=dev)
+    bk8 = torch.empty_like(va8)
+    pv8 = torch.full((nl8,), 1 << 40, dtype=torch.int64, device=dev)
+    sz8 = codec.encode64_batch(va8, vo8[:-1], bb8, bo8[:-1], c8, pv8, flags=svb.DELTA)
+    dB8 = float((sz8.sum().item() - ((c8.to(torch.int64) + 3) // 4).sum().item()) / tot8)
+    codec.decode64_batch(bb8, bo8[:-1], bk8, vo8[:-1], c8, pv8, flags=svb.DELTA)
+    assert torch.equal(bk8, va8)
+    ops["batch_encode64"] = (lambda: codec.encode64_batch(va8, vo8[:-1], bb8, bo8[:-1], c8, pv8, flags=svb.DELTA, sizes=sz8), (8.25 + dB8) * tot8)
+    ops["batch_decode64"] = (lambda: codec.decode64_batch(bb8, bo8[:-1], bk8, vo8[:-1], c8, pv8, flags=svb.DELTA, sizes=sz8), (8.25 + dB8) * tot8)
 if want("batch"):
     nl = 1 << 20
     counts, voff, vals = gen_posting_lists(torch, list_lengths(nl, 20241218), 1234, dev)
