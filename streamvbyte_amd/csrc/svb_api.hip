@@ -1000,7 +1000,7 @@ int svbgpu_decode64(unsigned flags, const uint8_t* d_in, uint64_t* d_out, uint32
     hipLaunchKernelGGL(k_multi_offsets, dim3(nblk), dim3(1024), 0, S(stream), wg, (u64)grid, blk, wg);
   }
 #define SVB_DEC64(D, Z)                                                                                          \
-  SVB_NT_SWITCH_023(nt_policy(options(), 0, 8ull * count) & kNtStores, NTV,                                      \
+  SVB_NT_SWITCH_023(nt_policy(options(), (count + 3ull) / 4 + count, 8ull * count), NTV,                         \
                     hipLaunchKernelGGL((k_decode64<D, Z, NTV>), dim3(grid), dim3(kBlock), 0, S(stream), d_in, d_out, \
                                        count, dir, d_consumed, (u64)prev, wg))
   if (d) { if (z) SVB_DEC64(true, true) else SVB_DEC64(true, false) }
