@@ -503,7 +503,18 @@ def main():
             "sorted_entries": int(sorted_b.numel()), "hits": k_hits, "ms": round(ms_i, 4),
             "Gvalues_per_s": round(n3 / ms_i / 1e6, 1),
             "parity": bool(k_hits == expect_hits.numel() and torch.equal(out[:k_hits], expect_hits))}
-        del post, s3, sorted_b, expect_hits
+        # ... and with that array delta-coded too: neither side is ever written out decoded
+        sb3, zb3 = codec.encode(sorted_b, variant=svb.V1234, flags=svb.DELTA, prev=0)
+        sb3 = sb3[: int(zb3.item()) + 16].clone()
+        nb3 = int(sorted_b.numel())
+        ms_x, _ = event_ms(torch, lambda: codec.intersect_streams(s3, n3, sb3, nb3, out=out), it)
+        _, n_hits = codec.intersect_streams(s3, n3, sb3, nb3, out=out)
+        codec.check()
+        k_hits = int(n_hits.item())
+        extra["delta_postings"]["intersect_streams"] = {
+            "values_b": nb3, "hits": k_hits, "ms": round(ms_x, 4), "Gvalues_per_s": round((n3 + nb3) / ms_x / 1e6, 1),
+            "parity": bool(k_hits == expect_hits.numel() and torch.equal(out[:k_hits], expect_hits))}
+        del post, s3, sorted_b, expect_hits, sb3
         # C3 mixed: 1-3 byte gaps, running sum wraps modulo 2^32, prev != 0; at 2^26 values and at the workload's size
         def mixed_gaps(n3b):
             r31 = torch.randint(0, 1 << 31, (n3b,), generator=g, device=device, dtype=torch.int64)

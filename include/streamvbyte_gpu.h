@@ -288,6 +288,24 @@ int svbgpu_decode_intersect(int variant, const uint8_t *d_in, uint32_t count, ui
                             uint64_t *d_consumed, void *stream);
 
 /*
+ * Two delta-coded streams intersected: d_out receives, in A's order, every value of
+ * stream A (count_a values, seed prev_a, coded as streamvbyte_delta_encode writes them,
+ * reference include/streamvbytedelta.h:19) that occurs in stream B; *d_n_out their
+ * number.  Neither stream is written out decoded: B's per-1024-value running sums serve
+ * as a skip list, and only the parts of B that a piece of A can meet are decoded, into
+ * on-chip memory.  B must ascend without wrapping past 2^32 (a posting list); A may be
+ * any stream (one that ascends is fastest).  d_out needs room for count_a values.  Both
+ * streams readable STREAMVBYTE_PADDING bytes past their end.  Workspace:
+ * svbgpu_intersect_workspace_bytes(count_a, count_b), 256-byte aligned.  No counterpart
+ * in the reference, whose callers decode both lists and then intersect.
+ */
+size_t svbgpu_intersect_workspace_bytes(uint32_t count_a, uint32_t count_b);
+int svbgpu_intersect_streams(int variant_a, const uint8_t *d_a, uint32_t count_a, uint32_t prev_a,
+                             int variant_b, const uint8_t *d_b, uint32_t count_b, uint32_t prev_b,
+                             uint32_t *d_out, uint64_t *d_n_out, void *d_workspace,
+                             size_t workspace_bytes, void *stream);
+
+/*
  * 64-bit values ("1248").  No counterpart in the reference, whose values are
  * uint32_t (include/streamvbyte.h:23 there); the container is the reference's:
  * (count + 3) / 4 control bytes, then the data bytes; four 2-bit codes per

@@ -361,6 +361,25 @@ class DeviceCodec:
                                                     self._res_ptr(1), self._stream()), "svbgpu_decode_intersect")
         return out, self.res[4:5], self.res[1:2]
 
+    def intersect_streams(self, stream_a, count_a, stream_b, count_b, out=None, variant_a=V1234, prev_a=0,
+                          variant_b=V1234, prev_b=0):
+        """Two delta-coded streams (B ascending) -> (matches buffer, n_matches_tensor[1]): the values of A
+        that occur in B, in A's order; neither stream is written out decoded."""
+        torch = self.torch
+        assert stream_a.is_contiguous() and stream_b.is_contiguous()
+        need = self.lib.svbgpu_intersect_workspace_bytes(count_a, count_b)
+        ws = getattr(self, "_sx_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._sx_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty(max(count_a, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_intersect_streams(variant_a, stream_a.data_ptr(), count_a, prev_a & 0xFFFFFFFF,
+                                                     variant_b, stream_b.data_ptr(), count_b, prev_b & 0xFFFFFFFF,
+                                                     out.data_ptr(), self._res_ptr(4), ws.data_ptr(), ws.numel(),
+                                                     self._stream()), "svbgpu_intersect_streams")
+        return out, self.res[4:5]
+
     def decode_plan(self, stream, count, variant=V1234):
         with self.torch.cuda.device(self.device):
             _check(self.lib.svbgpu_decode_plan(variant, stream.data_ptr(), count, self.ws.data_ptr(),
@@ -474,3 +493,6 @@ class DeviceCodec:
         """Synchronise and raise if a device scan gave up (never expected)."""
         with self.torch.cuda.device(self.device):
             _check(self.lib.svbgpu_check_status(self.ws.data_ptr(), self._stream()), "svbgpu_check_status")
+            sx = getattr(self, "_sx_ws", None)  # the workspace of intersect_streams, if it was ever used
+            if sx is not None:
+                _check(self.lib.svbgpu_check_status(sx.data_ptr(), self._stream()), "svbgpu_check_status")

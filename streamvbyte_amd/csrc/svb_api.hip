@@ -109,6 +109,7 @@ struct Options {
   int decode_shortcut;   // plain decoder: shortcut for wave tiles of all-zero keys
   int delta_lookback;    // 1: single-pass look-back differential decoder, 0: two streaming passes
   int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8)
+  int encode64_waves;    // waves (= wave tiles) per workgroup of k_encode64_lb (4, 8 or 16)
   int encode_qw;         // wave tiles per wave in k_encode (1, 2 or 4)
   int batch_lists_per_wave;  // row/wave batched kernels: lists per wave of a launch, 0 = one grid that fills the device
   int batch_chunk;       // batched calls: -1 chunked kernels, streams per wavefront chosen from the batch size;
@@ -125,7 +126,7 @@ struct Options {
   int nt_force;          // -1: by size; 0..3: this policy whatever the size (bit 0 loads, bit 1 stores)
   unsigned lb_tag2 = 0;  // not a knob: the look-back tag of the running call (LbWords::tag2), set by prepare_lookback
 };
-std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8},
+std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8}, o_encode64_waves{8},
     o_encode_qw{4}, o_encode_pipeline{1}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
     o_host_stage_pageable{1}, o_nt_threshold_mib{128}, o_nt_force{-1}, o_host_pointers_only{0};
 inline Options options() {
@@ -136,6 +137,7 @@ inline Options options() {
   o.decode_shortcut = o_decode_shortcut.load(rl);
   o.delta_lookback = o_delta_lookback.load(rl);
   o.encode_waves = o_encode_waves.load(rl);
+  o.encode64_waves = o_encode64_waves.load(rl);
   o.encode_qw = o_encode_qw.load(rl);
   o.encode_pipeline = o_encode_pipeline.load(rl);
   o.encode_ticket_early = o_encode_ticket_early.load(rl);
@@ -563,6 +565,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"decode_grid_per_cu", &o_decode_per_cu, [](int v) { return v >= 0; }},
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
+      {"encode64_waves", &o_encode64_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
       {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 2; }},
       {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
@@ -939,6 +942,70 @@ int svbgpu_decode_intersect(int variant, const uint8_t* d_in, uint32_t count, ui
   return SVBGPU_OK;
 }
 
+extern "C++" {
+// The pre-pass both sides of svbgpu_intersect_streams get: directory, then the value preceding every wave tile.
+template <int V>
+void launch_value_prefix(const uint8_t* d_in, uint32_t count, uint32_t prev, void* ws, hipStream_t st) {
+  const WsLayout L = ws_layout(count);
+  const unsigned grid = stream_grid((L.n_wt + kWaves - 1) / kWaves, options().decode_per_cu);
+  u32* vsum = ws_at<u32>(ws, L.off_wt_vsum);
+  u32* blk = ws_at<u32>(ws, L.off_blk);
+  const unsigned nblk = (unsigned)((L.n_wt + 1023) / 1024);
+  hipLaunchKernelGGL((k_value_sums<V, false>), dim3(grid), dim3(kBlock), 0, st, d_in, count, ws_dir(ws, L), vsum);
+  hipLaunchKernelGGL(k_scan_u32_blocks, dim3(nblk), dim3(kBlock), 0, st, vsum, (u32)L.n_wt, blk);
+  hipLaunchKernelGGL(k_scan_u32_top, dim3(1), dim3(1024), 0, st, blk, nblk, prev);
+}
+}  // extern "C++"
+
+// two workspaces back to back, then one (first, end) pair of wave tiles of B per wavefront of k_stream_intersect
+static size_t sx_range_bytes(const WsLayout& La) { return align256(8 * (La.n_wt / kSxQ + 2)); }
+size_t svbgpu_intersect_workspace_bytes(uint32_t count_a, uint32_t count_b) {
+  const WsLayout La = ws_layout(count_a);
+  return La.total + ws_layout(count_b).total + sx_range_bytes(La);
+}
+
+int svbgpu_intersect_streams(int variant_a, const uint8_t* d_a, uint32_t count_a, uint32_t prev_a, int variant_b,
+                             const uint8_t* d_b, uint32_t count_b, uint32_t prev_b, uint32_t* d_out,
+                             uint64_t* d_n_out, void* ws, size_t ws_bytes, void* stream) {
+  if (bad_variant(variant_a) || bad_variant(variant_b) || !d_n_out) return SVBGPU_EINVAL;
+  if (count_a == 0 || count_b == 0) return fill_u32(d_n_out, 0u, 8, S(stream));
+  if (!d_a || !d_b || !d_out) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const WsLayout La = ws_layout(count_a), Lb = ws_layout(count_b);
+  if (!ws || ((uintptr_t)ws & 255u) || ws_bytes < La.total + Lb.total + sx_range_bytes(La)) return SVBGPU_EWORKSPACE;
+  void* ws_b = static_cast<char*>(ws) + La.total;  // totals are multiples of 256
+  uint2* range = reinterpret_cast<uint2*>(static_cast<char*>(ws_b) + Lb.total);
+  hipStream_t st = S(stream);
+  int rc = clear_lookback(count_a, ws, st);
+  if (rc) return rc;
+  rc = build_directory(variant_a, d_a, count_a, ws, st);
+  if (rc) return rc;
+  rc = build_directory(variant_b, d_b, count_b, ws_b, st);
+  if (rc) return rc;
+  if (variant_a == SVBGPU_1234) launch_value_prefix<V1234>(d_a, count_a, prev_a, ws, st);
+  else launch_value_prefix<V0124>(d_a, count_a, prev_a, ws, st);
+  if (variant_b == SVBGPU_1234) launch_value_prefix<V1234>(d_b, count_b, prev_b, ws_b, st);
+  else launch_value_prefix<V0124>(d_b, count_b, prev_b, ws_b, st);
+  const u32 n_tiles = (u32)((La.n_wt + kSxWaves * kSxQ - 1) / (kSxWaves * kSxQ));
+  const u32 n_sx_waves = (u32)((La.n_wt + kSxQ - 1) / kSxQ);
+  hipLaunchKernelGGL(k_stream_bounds, dim3((n_sx_waves + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                     ws_at<u32>(ws, La.off_wt_vsum), ws_at<u32>(ws, La.off_blk), (u32)La.n_wt,
+                     ws_at<u32>(ws_b, Lb.off_wt_vsum), ws_at<u32>(ws_b, Lb.off_blk), (u32)Lb.n_wt, range);
+#define SVB_SX_LAUNCH(VA, VB)                                                                                   \
+  hipLaunchKernelGGL((k_stream_intersect<VA, VB, kSxWaves>), dim3(n_tiles), dim3(kSxWaves * 64), 0, st, d_a, count_a, \
+                     ws_dir(ws, La), ws_at<u32>(ws, La.off_wt_vsum), ws_at<u32>(ws, La.off_blk), d_b, count_b,  \
+                     ws_dir(ws_b, Lb), ws_at<u32>(ws_b, Lb.off_wt_vsum), ws_at<u32>(ws_b, Lb.off_blk), range,   \
+                     d_out, d_n_out, n_tiles, ws_hdr(ws), lb_words(ws, La, 0u))
+  if (variant_a == SVBGPU_1234) {
+    if (variant_b == SVBGPU_1234) SVB_SX_LAUNCH(V1234, V1234); else SVB_SX_LAUNCH(V1234, V0124);
+  } else {
+    if (variant_b == SVBGPU_1234) SVB_SX_LAUNCH(V0124, V1234); else SVB_SX_LAUNCH(V0124, V0124);
+  }
+#undef SVB_SX_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
 int svbgpu_encode64(unsigned flags, const uint64_t* d_in, uint32_t count, uint8_t* d_out, uint64_t prev, void* ws,
                     size_t ws_bytes, uint64_t* d_written, void* stream) {
   if (bad_flags(flags)) return SVBGPU_EINVAL;
@@ -954,19 +1021,29 @@ int svbgpu_encode64(unsigned flags, const uint64_t* d_in, uint32_t count, uint8_
   rc = prepare_lookback(count, ws, S(stream), &tag2);
   if (rc) return rc;
   const WsLayout L = ws_layout(count);
-  constexpr int NW = 8;  // wave tiles per look-back tile
-  const unsigned n_tiles = (unsigned)((L.n_wt + NW - 1) / NW);
-  const unsigned grid = stream_grid(n_tiles, 2);
   const LbWords lbw = lb_words(ws, L, tag2);
   const Options o = options();
   const bool d = flags & SVBGPU_DELTA, z = flags & SVBGPU_ZIGZAG;
-#define SVB_ENC64(D, Z)                                                                                              \
-  SVB_NT_SWITCH_013(nt_policy(o, 8ull * count, (count + 3ull) / 4 + count), NTV,                                     \
-                    hipLaunchKernelGGL((k_encode64_lb<D, Z, NW, NTV>), dim3(grid), dim3(NW * 64), 0, S(stream), d_in, \
-                                       count, n_tiles, d_out, (u64)prev, ws_hdr_slot(ws, tag2), lbw, d_written))
+  // NW = wave tiles (= waves) per look-back tile
+#define SVB_ENC64_NW(D, Z, NW, PER_CU)                                                                               \
+  {                                                                                                                  \
+    const unsigned n_tiles = (unsigned)((L.n_wt + NW - 1) / NW);                                                     \
+    const unsigned grid = stream_grid(n_tiles, PER_CU);                                                              \
+    SVB_NT_SWITCH_013(nt_policy(o, 8ull * count, (count + 3ull) / 4 + count), NTV,                                   \
+                      hipLaunchKernelGGL((k_encode64_lb<D, Z, NW, NTV>), dim3(grid), dim3(NW * 64), 0, S(stream),     \
+                                         d_in, count, n_tiles, d_out, (u64)prev, ws_hdr_slot(ws, tag2), lbw,         \
+                                         d_written))                                                                 \
+  }
+#define SVB_ENC64(D, Z)                                          \
+  {                                                              \
+    if (o.encode64_waves == 16) SVB_ENC64_NW(D, Z, 16, 1)        \
+    else if (o.encode64_waves == 4) SVB_ENC64_NW(D, Z, 4, 4)     \
+    else SVB_ENC64_NW(D, Z, 8, 2)                                \
+  }
   if (d) { if (z) SVB_ENC64(true, true) else SVB_ENC64(true, false) }
   else   { if (z) SVB_ENC64(false, true) else SVB_ENC64(false, false) }
 #undef SVB_ENC64
+#undef SVB_ENC64_NW
   HIP_TRY(hipGetLastError());
   return finish_lookback(ws, S(stream), tag2);
 }

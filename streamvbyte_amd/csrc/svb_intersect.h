@@ -320,4 +320,333 @@ __global__ __launch_bounds__(kBlock, 4) void k_delta_intersect(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Two delta-coded streams intersected without either being written out decoded.
+//
+// Both streams get the pre-pass of the two-pass differential decoder, which leaves
+// for every wave tile the value that precedes it (vpre[wt] + blk[wt >> 10]): for an
+// ascending stream B that is a sorted skip list with one entry per 1024 values.  A
+// wavefront decodes 2048 values of stream A into registers, finds with two 64-way
+// searches in B's skip list the wave tiles of B that can hold any of them, decodes
+// those one at a time into its LDS image -- as a bitmap when the tile's values lie
+// within 32768 of each other, else as the sorted values themselves -- and looks
+// its own values up there.  Hit counts travel through the look-back as in
+// k_delta_intersect.  B must ascend without wrapping; A may be anything (a wave
+// whose values jump about walks more of B).
+constexpr int kSxQ = 2;                 // wave tiles of stream A per wavefront
+constexpr int kSxWaves = 4;             // wavefronts per workgroup = per look-back tile (16 measured 3-10 % slower)
+
+// First i in [0, n) with f(i) >= key (GT false) or f(i) > key (GT true), n if none; f ascending.
+// key and the result are wave-uniform; 64 probes a step.
+template <bool GT, class F>
+__device__ __forceinline__ u32 wave_bound_fn(F f, u32 n, u32 key, int lane) {
+  u32 lo = 0, hi = n;
+  while (lo < hi) {
+    const u32 step = (hi - lo + 63u) >> 6;
+    const u64 idx = (u64)lo + (u64)lane * step;
+    bool ok = true;
+    if (idx < hi) {
+      const u32 x = f((u32)idx);
+      ok = GT ? x > key : x >= key;
+    }
+    const u64 m = __ballot(ok);
+    const u32 first = m ? (u32)__builtin_ctzll(m) : 64u;
+    if (first == 0) {
+      hi = lo;
+    } else {
+      const u64 nh = (u64)lo + (u64)first * step;
+      lo = lo + (first - 1) * step + 1;
+      hi = (u32)min((u64)hi, nh);
+    }
+  }
+  return lo;
+}
+
+// range[w] = the wave tiles [x, y) of stream B that wavefront w of k_stream_intersect (wave tiles kSxQ w ..
+// of stream A) can meet if A ascends there: from the tile ahead of the first whose preceding value is >= the
+// value preceding the wave's first, to the last whose preceding value is <= the wave's last value (= the
+// value preceding the next wave's first).  One thread per wavefront; the last wavefront searches for itself.
+__global__ __launch_bounds__(kBlock) void k_stream_bounds(const u32* __restrict__ a_vpre, const u32* __restrict__ a_blk,
+                                                          u32 a_nwt, const u32* __restrict__ b_vpre,
+                                                          const u32* __restrict__ b_blk, u32 b_nwt,
+                                                          uint2* __restrict__ range) {
+  const u32 w = blockIdx.x * kBlock + threadIdx.x;
+  const u32 wt = w * kSxQ;
+  if (wt + kSxQ >= a_nwt) return;
+  const u32 key_lo = a_vpre[wt] + a_blk[wt >> 10];
+  const u32 key_hi = a_vpre[wt + kSxQ] + a_blk[(wt + kSxQ) >> 10];
+  u32 lo = 0, hi = b_nwt;
+  while (lo < hi) {  // first i with before_b(i) >= key_lo
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (b_vpre[mid] + b_blk[mid >> 10] < key_lo) lo = mid + 1; else hi = mid;
+  }
+  const u32 x = lo ? lo - 1u : 0u;
+  hi = b_nwt;  // first i with before_b(i) > key_hi; not below lo when key_hi >= key_lo
+  if (key_hi < key_lo) lo = 0;
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (b_vpre[mid] + b_blk[mid >> 10] <= key_hi) lo = mid + 1; else hi = mid;
+  }
+  range[w] = make_uint2(x, lo);
+}
+
+template <int VA, int VB, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_stream_intersect(
+    const u8* __restrict__ a_in, u32 a_count, Dir a_dir, const u32* __restrict__ a_vpre,
+    const u32* __restrict__ a_blk, const u8* __restrict__ b_in, u32 b_count, Dir b_dir,
+    const u32* __restrict__ b_vpre, const u32* __restrict__ b_blk, const uint2* __restrict__ range,
+    u32* __restrict__ out, u64* __restrict__ n_out, u32 n_tiles, WsHeader* __restrict__ hdr, LbWords lb) {
+  __shared__ WaveLds s_lds[NW];
+  __shared__ u32 s_wave_tot[NW];
+  __shared__ u64 s_prefix;
+  __shared__ u32 s_tile;
+  const int lane = lane_id(), wave = wave_id();
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(&hdr->ticket, 1u);
+    if (t == n_tiles - 1u) __hip_atomic_store(&hdr->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tile = t;
+  }
+  __syncthreads();
+  const u32 tile = __builtin_amdgcn_readfirstlane(s_tile);
+  WaveLds& S = s_lds[wave];
+  const u64 a_keylen = ((u64)a_count + 3) >> 2;
+  const u32 a_nwt = (u32)((a_keylen + kWtKeys - 1) / kWtKeys);
+  const u8* a_data = a_in + a_keylen;
+  const u32 wt0 = (tile * NW + wave) * kSxQ;
+
+  const u64 b_keylen = ((u64)b_count + 3) >> 2;
+  const u32 b_nwt = (u32)((b_keylen + kWtKeys - 1) / kWtKeys);
+  const u8* b_data = b_in + b_keylen;
+  // What a wave tile of B needs before it can be decoded, requested a tile ahead of its use.
+  struct BTile { u32 w; u64 doff; u32 before; };
+  DirWalk bwalk;
+  auto fetch = [&](u32 t) {
+    BTile x;
+    const u64 koff = (u64)t * kWtKeys + 4 * lane;
+    x.w = koff < b_keylen ? ld_u32(b_in + koff) : 0u;
+    x.doff = bwalk.offset(b_dir, t, lane);
+    x.before = b_vpre[t] + b_blk[t >> 10];
+    return x;
+  };
+  // the pre-pass's guess of the wave's share of B (right when A ascends here), and its first tile on the way
+  const bool guessed = wt0 + kSxQ < a_nwt;
+  uint2 guess = make_uint2(0u, 0u);
+  if (guessed) {
+    const uint2 g = range[wt0 / kSxQ];
+    guess = make_uint2((u32)__builtin_amdgcn_readfirstlane((int)g.x), (u32)__builtin_amdgcn_readfirstlane((int)g.y));
+  }
+  BTile cur{};
+  if (guess.x < guess.y) cur = fetch(guess.x);
+
+  // ---- the wave's values of stream A ----
+  uint4 v[kSxQ][4];
+  u32 nints[kSxQ];
+  u32 before_a = 0, last_a = 0;
+  {
+    u32 w[kSxQ], vpre[kSxQ];
+    u64 doff[kSxQ];
+    DirWalk walk;
+#pragma unroll
+    for (int q = 0; q < kSxQ; ++q) {
+      const u32 wt = wt0 + q;
+      w[q] = 0; doff[q] = 0; vpre[q] = 0; nints[q] = 0;
+      if (wt < a_nwt) {
+        const u64 koff = (u64)wt * kWtKeys + 4 * lane;
+        if (koff < a_keylen) w[q] = ld_u32(a_in + koff);
+        doff[q] = walk.offset(a_dir, wt, lane);
+        vpre[q] = a_vpre[wt] + a_blk[wt >> 10];
+        nints[q] = (u32)min((u64)kWtInts, (u64)a_count - (u64)wt * kWtInts);
+      }
+    }
+    before_a = last_a = vpre[0];
+#pragma unroll
+    for (int q = 0; q < kSxQ; ++q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
+      if (nints[q]) {
+        decode_wavetile<VA, false>(w[q], nints[q], a_data + doff[q], lane, S, v[q]);
+        u32 run = vpre[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint4& c = v[q][j];
+          c.y += c.x; c.z += c.y; c.w += c.z;
+          const u32 incl = wave_scan_incl(c.w, lane);
+          const u32 ex = incl - c.w + run;
+          run += wave_last(incl);
+          c.x += ex; c.y += ex; c.z += ex; c.w += ex;
+        }
+        last_a = run;
+      }
+    }
+  }
+  u32 vmax = 0, vmin_inv = 0;
+#pragma unroll
+  for (int q = 0; q < kSxQ; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 m = valid4(nints[q], j, lane);
+      const uint4& c = v[q][j];
+      if (m & 1u) { vmax = max(vmax, c.x); vmin_inv = max(vmin_inv, ~c.x); }
+      if (m & 2u) { vmax = max(vmax, c.y); vmin_inv = max(vmin_inv, ~c.y); }
+      if (m & 4u) { vmax = max(vmax, c.z); vmin_inv = max(vmin_inv, ~c.z); }
+      if (m & 8u) { vmax = max(vmax, c.w); vmin_inv = max(vmin_inv, ~c.w); }
+    }
+  vmax = wave_max(vmax);
+  const u32 vmin = ~wave_max(vmin_inv);
+
+  // ---- the wave tiles of stream B that can hold any of them ----
+  u32 t_lo = 0, t_hi = 0;  // [t_lo, t_hi)
+  if (nints[0] && b_count) {
+    if (guessed && vmin >= before_a && vmax <= last_a) {  // ascending as far as it matters
+      t_lo = guess.x;
+      t_hi = guess.y;
+    } else {
+      auto before = [&](u32 i) { return b_vpre[i] + b_blk[i >> 10]; };  // the value preceding wave tile i of B
+      // wave tile t holds values from before(t) to before(t + 1): the first that can reach vmin is the one
+      // ahead of the first whose predecessor is already >= vmin; the last is the last with before(t) <= vmax
+      const u32 i_lo = wave_bound_fn<false>(before, b_nwt, vmin, lane);
+      t_lo = i_lo ? i_lo - 1u : 0u;
+      t_hi = wave_bound_fn<true>(before, b_nwt, vmax, lane);
+      if (t_lo < t_hi && !(guess.x < guess.y && guess.x == t_lo)) cur = fetch(t_lo);
+    }
+  }
+
+  u32* buf = reinterpret_cast<u32*>(S.data);
+  static_assert(sizeof(S.data) >= 4096, "the wave's LDS image holds the 1024 values of a wave tile of B");
+  u32 hits = 0;  // bit q*16 + j*4 + k
+  for (u32 t = t_lo; t < t_hi; ++t) {
+    const BTile now = cur;
+    if (t + 1 < t_hi) cur = fetch(t + 1);
+    const u32 bn = (u32)min((u64)kWtInts, (u64)b_count - (u64)t * kWtInts);
+    uint4 c[4];
+    decode_wavetile<VB, false>(now.w, bn, b_data + now.doff, lane, S, c);
+    u32 run = now.before;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4& x = c[j];
+      x.y += x.x; x.z += x.y; x.w += x.z;
+      const u32 incl = wave_scan_incl(x.w, lane);
+      const u32 ex = incl - x.w + run;
+      run += wave_last(incl);
+      x.x += ex; x.y += ex; x.z += ex; x.w += ex;
+    }
+    const u32 t_first = (u32)__builtin_amdgcn_readfirstlane((int)c[0].x);
+    const u32 t_last = run;  // absent values are zero deltas: the running sum ends on the last value
+    if (t_last < vmin || t_first > vmax) continue;  // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // A bitmap of B's values (one LDS read per value of A) where the values to enter lie within 32768 of each
+    // other: the whole wave tile when it is that dense, else only its values inside the span of the wave's own.
+    u32 inr = 0xFFFFu, first = t_first, last = t_last, below = 0;
+    const bool whole = t_last - t_first < 32768u;
+    if (whole) {
+      inr = valid4(bn, 0, lane) | (valid4(bn, 1, lane) << 4) | (valid4(bn, 2, lane) << 8) | (valid4(bn, 3, lane) << 12);
+    } else {
+      u32 fmax = 0, fmin_inv = 0;
+      inr = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 m = valid4(bn, j, lane);
+        const u32 x[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool valid = (m >> k) & 1u;
+          const bool in = valid && x[k] >= vmin && x[k] <= vmax;
+          below += (valid && x[k] < vmin) ? 1u : 0u;
+          if (in) {
+            inr |= 1u << (4 * j + k);
+            fmax = max(fmax, x[k]);
+            fmin_inv = max(fmin_inv, ~x[k]);
+          }
+        }
+      }
+      if (__ballot(inr != 0u) == 0ull) continue;  // wave-uniform: nothing of this tile can meet the wave's values
+      first = ~wave_max(fmin_inv);
+      last = wave_max(fmax);
+    }
+    if (last - first < 32768u) {
+      const u32 span = last - first;  // a value outside it (B not ascending) is dropped, never written out of bounds
+      const u32 nw = (span >> 5) + 1u;
+      for (u32 e = lane; e < nw; e += 64) buf[e] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 d0 = c[j].x - first, d1 = c[j].y - first, d2 = c[j].z - first, d3 = c[j].w - first;
+        if ((inr & (1u << (4 * j))) && d0 <= span) atomicOr(&buf[d0 >> 5], 1u << (d0 & 31u));
+        if ((inr & (2u << (4 * j))) && d1 <= span) atomicOr(&buf[d1 >> 5], 1u << (d1 & 31u));
+        if ((inr & (4u << (4 * j))) && d2 <= span) atomicOr(&buf[d2 >> 5], 1u << (d2 & 31u));
+        if ((inr & (8u << (4 * j))) && d3 <= span) atomicOr(&buf[d3 >> 5], 1u << (d3 & 31u));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < kSxQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          hits |= lds_bits4(buf, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 m = valid4(bn, j, lane);
+        uint4 x = c[j];
+        if (!(m & 1u)) x.x = 0xFFFFFFFFu;
+        if (!(m & 2u)) x.y = 0xFFFFFFFFu;
+        if (!(m & 4u)) x.z = 0xFFFFFFFFu;
+        if (!(m & 8u)) x.w = 0xFFFFFFFFu;
+        *reinterpret_cast<uint4*>(buf + 4 * (j * 64 + lane)) = x;  // value i of the wave tile at buf[i]
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // B ascends, so the values inside the span are buf[lo .. lo + len): search a window of the array that
+      // holds them -- a power of two of entries, moved down where it would reach past the array's end (what
+      // it then takes in below lo is smaller than every candidate and sorted with the rest)
+      const u32 lo = wave_sum(below), len = wave_sum((u32)__popc(inr));
+      const u32 top = len > 1u ? 1u << (31 - __builtin_clz(len - 1u)) : 0u;
+      const u32 win = top ? 2u * top : 1u;
+      const u32 wb = min(lo, (u32)kWtInts - win);
+#pragma unroll
+      for (int q = 0; q < kSxQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          hits |= lds_find4(buf + wb, win, top, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- the tile's place in the output ----
+  const u32 wave_tot = wave_sum((u32)__popc(hits));
+  if (lane == 0) s_wave_tot[wave] = wave_tot;
+  __syncthreads();
+  if (wave == 0) {
+    u32 tile_tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tile_tot += s_wave_tot[w];
+    const u64 excl = lb2_exclusive_prefix<1>(lb, tile, tile_tot, lane, &hdr->error);
+    if (lane == 0) {
+      s_prefix = excl;
+      if (tile == n_tiles - 1) *n_out = excl + tile_tot;
+    }
+  }
+  __syncthreads();
+  u64 base = s_prefix;
+  for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+  if (wave_tot == 0) return;
+#pragma unroll
+  for (int q = 0; q < kSxQ; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 m = (hits >> (q * 16 + j * 4)) & 15u;
+      const u32 cnt = (u32)__popc(m);
+      const u32 incl = wave_scan_incl(cnt, lane);
+      u32* p = out + base + (incl - cnt);
+      base += wave_last(incl);
+      const uint4& r = v[q][j];
+      if (m & 1u) *p++ = r.x;
+      if (m & 2u) *p++ = r.y;
+      if (m & 4u) *p++ = r.z;
+      if (m & 8u) *p++ = r.w;
+    }
+}
+
 }  // namespace svb

@@ -91,6 +91,12 @@ def test_lookback_kernels_are_exact_under_delays(oracle, stressed, n):
     want = post[np.isin(post, probe)]
     assert int(nhits.item()) == want.size
     assert np.array_equal(to_np(hits[: want.size], np.uint32), want)
+    # ... and with the probe compressed as well (svbgpu_intersect_streams: the same chain of hit counts)
+    enc_b = oracle.encode(V1234, probe, True, 0)
+    hits, nhits = codec.intersect_streams(dev_stream(torch, enc), n, dev_stream(torch, enc_b), probe.size)
+    codec.check()
+    assert int(nhits.item()) == want.size
+    assert np.array_equal(to_np(hits[: want.size], np.uint32), want)
     # 64-bit values: the single-pass 1248 encoder chains its tiles the same way
     w = (rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
          >> (np.uint64(64) - (np.uint64(8) << rng.integers(0, 4, size=n).astype(np.uint64))))

@@ -624,6 +624,58 @@ def test_decode_intersect(torch_mod, codec, oracle, variant):
     assert int(n_out.item()) == 0 and int(used.item()) == 0
 
 
+@pytest.mark.parametrize("variant_a,variant_b", [(V1234, V1234), (V0124, V1234), (V1234, V0124)])
+def test_intersect_streams(torch_mod, codec, oracle, variant_a, variant_b):
+    """Two delta-coded streams intersected on the device = both decoded by the oracle, then numpy isin:
+    B sparser, as dense, denser than A; repeats in both; seeds; B of one value, of exactly one wave tile;
+    A that wraps or jumps about (B must ascend, A need not)."""
+    torch = torch_mod
+    rng = np.random.default_rng(190 + 2 * variant_a + variant_b)
+
+    def ascending(n, gap, start=0):
+        return (np.cumsum(rng.integers(0, gap, n, dtype=np.uint64)) + start).astype(np.uint32)
+
+    cases = []
+    for na in (1, 5, 1023, 1024, 1025, 2048, 2049, 8192, 8193, 70001, 300001):
+        for ratio in (0.02, 1.0, 17.0):
+            nb = max(1, int(na * ratio))
+            gap_a = 40
+            gap_b = max(2, int(gap_a / ratio))
+            cases.append((ascending(na, gap_a), 0, ascending(nb, gap_b), 0))
+    # wide gaps (no bitmap), seeds on both sides, B starting far above / below A
+    cases.append((ascending(100000, 3000, 77), 77, ascending(90000, 3300, 5), 5))
+    cases.append((ascending(50000, 40, 1 << 20), 1 << 20, ascending(50000, 40), 0))
+    cases.append((ascending(50000, 40), 0, ascending(50000, 40, 1 << 21), 1 << 21))
+    cases.append((ascending(5000, 40), 0, np.array([4321], dtype=np.uint32), 0))
+    cases.append((ascending(5000, 3), 0, ascending(1024, 9), 0))
+    # A wraps past 2^32 / jumps about; B ascends
+    cases.append(((np.cumsum(rng.integers(0, 40, 70000, dtype=np.uint64)) + 0xFFFF0000).astype(np.uint32), 0,
+                  np.unique(rng.integers(0, 1 << 32, 400000, dtype=np.uint64).astype(np.uint32)), 0))
+    cases.append((GENERATORS["width_mix"](rng, 20000), 9,
+                  np.unique(GENERATORS["width_mix"](rng, 60000)), 0))
+    for a, prev_a, b, prev_b in cases:
+        b = np.sort(b)
+        if b.size > 3:
+            b[b.size // 2] = b[b.size // 2 - 1]        # a repeat in B
+        sa = oracle.encode(variant_a, a, True, prev_a)
+        sb = oracle.encode(variant_b, b, True, prev_b)
+        expect = a[np.isin(a, b)]
+        out, n_out = codec.intersect_streams(dev_stream(torch, sa), a.size, dev_stream(torch, sb), b.size,
+                                             variant_a=variant_a, prev_a=prev_a, variant_b=variant_b, prev_b=prev_b)
+        assert int(n_out.item()) == expect.size, (a.size, b.size)
+        assert np.array_equal(to_np(out[: expect.size], np.uint32), expect), (a.size, b.size)
+    # every value of A in B; an empty side
+    a = ascending(40000, 50)
+    sa = oracle.encode(variant_a, a, True, 0)
+    sb = oracle.encode(variant_b, a, True, 0)
+    out, n_out = codec.intersect_streams(dev_stream(torch, sa), a.size, dev_stream(torch, sb), a.size,
+                                         variant_a=variant_a, variant_b=variant_b)
+    assert int(n_out.item()) == a.size and np.array_equal(to_np(out[: a.size], np.uint32), a)
+    out, n_out = codec.intersect_streams(dev_stream(torch, sa), a.size, dev_stream(torch, np.zeros(0, dtype=np.uint8)), 0,
+                                         variant_a=variant_a, variant_b=variant_b)
+    assert int(n_out.item()) == 0
+
+
 @pytest.mark.parametrize("variant", [V1234, V0124])
 def test_validate_batch(torch_mod, codec, oracle, variant):
     """svbgpu_validate_batch = the oracle's validate_stream stream by stream, for right and wrong lengths,

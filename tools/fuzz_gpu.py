@@ -132,6 +132,15 @@ while time.time() < t_end:
         codec.check()
         assert int(u.item()) == sa.size and int(k.item()) == exp_hits.size, ("intersect count", m, pv) + tag
         assert np.array_equal(to_np(o[: exp_hits.size], np.uint32), exp_hits), ("intersect", m, pv) + tag
+        # the same with both sides compressed (B ascending, its own variant and seed)
+        vb = int(rng.integers(0, 2))
+        pb = int(b[0]) if (b.size and rng.random() < 0.3) else 0
+        sb = oracle.encode(vb, b, True, pb)
+        o, k = codec.intersect_streams(dev_stream(torch, sa), n, dev_stream(torch, sb), b.size, variant_a=variant,
+                                       prev_a=pv, variant_b=vb, prev_b=pb)
+        codec.check()
+        assert int(k.item()) == exp_hits.size, ("stream intersect count", m, pv, vb) + tag
+        assert np.array_equal(to_np(o[: exp_hits.size], np.uint32), exp_hits), ("stream intersect", m, pv, vb) + tag
 codec.lib.svbgpu_set_option(b"encode_tile", 4)
 codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
 print(f"fuzz ok: {it} cases, seed {seed}")

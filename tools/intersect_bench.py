@@ -60,3 +60,29 @@ for label, m in (("1/64 as dense", n // 64), ("1/8 as dense", n // 8), ("as dens
     print(f"  sorted array {label:13s} ({b.numel():>10d} entries): {t:.3f} ms, {k:>10d} hits, "
           f"{n / t / 1e6:.1f} Gvalues/s, {algo / t / 1e6:.0f} GB/s of stream+array+hits")
     del b, du, bu, pos, ref
+
+# ---- both sides compressed: svbgpu_intersect_streams against "decode B, then svbgpu_decode_intersect" ----
+print("stream x stream (svbgpu_intersect_streams); B = a delta-coded ascending stream")
+for label, m in (("1/64 as dense", n // 64), ("1/8 as dense", n // 8), ("as dense", n), ("4x as dense", min(4 * n, 1 << 30))):
+    b = torch.randint(0, min(top, (1 << 31) - 1), (m,), generator=g, device=dev, dtype=torch.int64)
+    b = torch.unique(b).to(torch.int32)
+    nb = b.numel()
+    cb = svb.DeviceCodec(nb)
+    sb, size_b = cb.encode(b, variant=svb.V1234, flags=svb.DELTA)
+    size_b = int(size_b.item())
+    t = timed(lambda: codec.intersect_streams(stream, n, sb, nb, out=out))
+    _, n_out = codec.intersect_streams(stream, n, sb, nb, out=out)
+    k = int(n_out.item())
+    decb = torch.empty(nb, dtype=torch.int32, device=dev)
+
+    def two_step():
+        cb.decode(sb, nb, out=decb, variant=svb.V1234, flags=svb.DELTA)
+        codec.decode_intersect(stream, n, decb, out=dec, variant=svb.V1234)
+    t2 = timed(two_step)
+    _, n_ref, _ = codec.decode_intersect(stream, n, decb, out=dec, variant=svb.V1234)
+    assert int(n_ref.item()) == k and torch.equal(dec[:k], out[:k]), (label, int(n_ref.item()), k)
+    algo = size + size_b + 4 * k
+    print(f"  B {label:13s} ({nb:>10d} values, {size_b / nb:.2f} B/value): {t:.3f} ms, {k:>10d} hits, "
+          f"{(n + nb) / t / 1e6:.1f} Gvalues/s of both streams, {algo / t / 1e6:.0f} GB/s of streams+hits; "
+          f"decode B then decode_intersect: {t2:.3f} ms")
+    del b, sb, decb, cb

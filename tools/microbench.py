@@ -148,6 +148,8 @@ if want("wide"):
     e8 = torch.empty((n8 + 3) // 4 + 8 * n8 + 32, dtype=torch.uint8, device=dev)
     ops["encode64"] = (lambda: codec.encode64(v8, out=e8), (8.25 + d8) * n8)
     ops["decode64"] = (lambda: codec.decode64(s8, n8, out=o8), (8.25 + d8) * n8)
+    for nw8 in (4, 16):
+        ops[f"encode64_waves{nw8}"] = (opt_with(b"encode64_waves", nw8, 8, lambda: codec.encode64(v8, out=e8)), (8.25 + d8) * n8)
 if want("wide_batch"):
     # 2^19 lists of 64-bit postings (the 32-bit posting lists' lengths and gaps, widened), delta coded
     nl8 = 1 << 19
