@@ -538,6 +538,9 @@ def main():
             ms_d2, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
             codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
             ms_d, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
+            codec.lib.svbgpu_set_option(b"scan_waves", 8)   # smaller tiles, every wave tile's bytes requested up front
+            ms_d8w, _ = event_ms(torch, lambda: codec.decode(s3, n3b, out=o3, flags=svb.DELTA, prev=0xDEADBEEF), it)
+            codec.lib.svbgpu_set_option(b"scan_waves", 16)
             codec.check()
             frac = lambda ms: round((4.25 + d3b) * n3b / ms / 1e6 / HBM_PEAK_GBS, 4)
             return {"n": n3b, "data_bytes_per_value": round(d3b, 4), "prev": "0xDEADBEEF",
@@ -546,6 +549,7 @@ def main():
                     "decode_GBps": round(4.0 * n3b / ms_d / 1e6, 1), "encode_GBps": round(4.0 * n3b / ms_e / 1e6, 1),
                     "encode_pipelined_GBps": round(4.0 * n3b / ms_ep / 1e6, 1),
                     "decode_roofline_frac": frac(ms_d), "encode_roofline_frac": frac(ms_e),
+                    "decode_scan_waves8_roofline_frac": frac(ms_d8w),
                     "encode_pipelined_roofline_frac": frac(ms_ep)}
         extra["delta_mixed_gaps"] = mixed_gaps(min(n, 1 << 26))
         if n > (1 << 26):

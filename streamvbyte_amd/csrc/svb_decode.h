@@ -282,6 +282,67 @@ __device__ __forceinline__ u32 decode_wavetile(u32 w, u32 nints, const u8* dp, i
   return total;
 }
 
+// decode_wavetile in two halves, for kernels whose waves take several wave tiles: the data loads of ALL of
+// them are sent before the first is used (a wave tile at a time, a wave has one tile's span in flight per
+// round trip).  span_issue requests the span [dp, dp + total) -- total from wavetile_data_bytes -- into K
+// registers per lane, decode_wavetile_landed scans the keys, drops the registers into the wave's LDS image
+// and extracts.  Spans of more than K * 64 chunks of 16 bytes do not fit: kSpanFits says so, and the caller
+// decodes such a wave tile with decode_wavetile.
+template <int V>
+__device__ __forceinline__ u32 wavetile_data_bytes(u32 w, u32 nints, int lane) {
+  const u32 nv = nints > 16u * lane ? min(nints - 16u * lane, 16u) : 0u;
+  return wave_sum(word_len<V>(mask_codes(w, nv), nv));
+}
+template <int K>
+struct SpanRegs {
+  uint4 r[K];
+  u32 shift, nch;
+};
+template <int K>
+__device__ __forceinline__ bool span_fits(const u8* dp, u32 total) {
+  return (((u32)((uintptr_t)dp & 15u) + total + 15u) >> 4) <= 64u * K;
+}
+template <int K, bool NTL>
+__device__ __forceinline__ void span_issue(const u8* dp, u32 total, int lane, SpanRegs<K>& R) {
+  R.shift = (u32)((uintptr_t)dp & 15u);
+  const uint4* src = reinterpret_cast<const uint4*>(dp - R.shift);
+  R.nch = (R.shift + total + 15u) >> 4;
+  const u32 last = R.nch - 1u;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    R.r[i] = make_uint4(0, 0, 0, 0);
+    if (64u * i < R.nch) R.r[i] = ld_stream16<NTL>(src + min((u32)lane + 64u * i, last));
+  }
+}
+template <int V, bool ZZ, int K>
+__device__ __forceinline__ u32 decode_wavetile_landed(u32 w, u32 nints, const SpanRegs<K>& R, int lane, WaveLds& S,
+                                                      uint4 (&v)[4]) {
+  const u32 nv = nints > 16u * lane ? min(nints - 16u * lane, 16u) : 0u;
+  const u32 total = scan_keys_to_entries<V, false>(w, nv, lane, S.ent);
+  uint4* d = reinterpret_cast<uint4*>(S.data);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const u32 c = lane + 64u * i;
+    if (c < R.nch) d[c] = R.r[i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 first = 4u * (j * 64 + lane);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (first < nints) {
+      r = extract_group<V>(S.ent[j * 64 + lane], R.shift, S.data);
+      if (ZZ) r = make_uint4(zz_dec(r.x), zz_dec(r.y), zz_dec(r.z), zz_dec(r.w));
+      const u32 left = nints - first;
+      if (left < 4) { r.w = 0; if (left < 3) r.z = 0; if (left < 2) r.y = 0; }
+    }
+    v[j] = r;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return total;
+}
+
 // ---- a group straight from registers (no LDS) ----------------------------------
 // bytes [o, o+4) of the 16-byte little-endian value d (o = 0..12), zero beyond
 __device__ __forceinline__ u32 bytes_at(const uint4& d, u32 o) {

@@ -118,15 +118,37 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
   // the kernel is bound by exactly that.
   if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(2); }
   bool direct[4];  // wave-uniform
+  // The other wave tiles' data spans are requested now as well, all four before the first is used, where a
+  // span fits kEarly registers per lane (up to 3 KiB: under three data bytes per value); the tile's byte count
+  // comes from its keys.  One wave tile at a time, a wave had 1-2 KiB in flight per round trip.
+  constexpr int kEarly = 3;
+#ifndef SVB_DELTA_WINDOW16
+#define SVB_DELTA_WINDOW16 0
+#endif
+  // wave tiles whose spans are in flight together: all four in workgroups of up to 8 waves.  The 16 waves of the
+  // large workgroup move in step, and anything requested ahead only deepens the burst they send together
+  // (measured at 2^28 values with 1.6 data bytes each: window 0 / 2 / 3 / 4 = 0.538 / 0.534 / 0.526 / 0.516 of
+  // the HBM peak; 8 waves with all four ahead 0.567, without 0.512), so there a wave tile's span is requested
+  // when its turn comes.
+  constexpr int kWindow = NW >= 16 ? SVB_DELTA_WINDOW16 : 4;
+  bool early[4];
+  u32 nints[4], tot[4];
+  SpanRegs<kEarly> span[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32 wt = wt0 + q;
-    direct[q] = wt < n_wt && (u64)wt * kWtInts + kWtInts <= count && __ballot(w[q] != 0u) == 0ull;
+    nints[q] = wt < n_wt ? (u32)min((u64)kWtInts, (u64)count - (u64)wt * kWtInts) : 0u;
+    direct[q] = nints[q] == (u32)kWtInts && __ballot(w[q] != 0u) == 0ull;
+    early[q] = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
     if (V == V1234 && direct[q]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[q][j].x = ld_u32(data_base + doff[q] + 4u * (j * 64 + lane));
+    } else if (!direct[q] && nints[q]) {
+      tot[q] = wavetile_data_bytes<V>(w[q], nints[q], lane);
+      early[q] = kWindow > 0 && span_fits<kEarly>(data_base + doff[q], tot[q]);
+      if (early[q] && q < kWindow) span_issue<kEarly, (NT & kNtLoads) != 0>(data_base + doff[q], tot[q], lane, span[q]);
     }
   }
 #pragma unroll
@@ -143,12 +165,13 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 3) void k_delta_decode(
         }
       }
       if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + (V == V1234 ? (u32)kWtInts : 0u);
-    } else if (wt < n_wt) {
-      const u64 int0 = (u64)wt * kWtInts;
-      const u32 nints = (u32)min((u64)kWtInts, (u64)count - int0);
-      const u32 total = decode_wavetile<V, ZZ, false, false, (NT & kNtLoads) != 0>(w[q], nints, data_base + doff[q], lane, S, v[q]);
+    } else if (nints[q]) {
+      const u32 total = early[q] ? decode_wavetile_landed<V, ZZ, kEarly>(w[q], nints[q], span[q], lane, S, v[q])
+                                 : decode_wavetile<V, ZZ, false, false, (NT & kNtLoads) != 0>(w[q], nints[q], data_base + doff[q], lane, S, v[q]);
       if (wt == n_wt - 1 && lane == 0 && consumed) *consumed = keylen + doff[q] + total;
     }
+    if (kWindow > 0 && q + kWindow < 4 && early[(q + kWindow) & 3])
+      span_issue<kEarly, (NT & kNtLoads) != 0>(data_base + doff[(q + kWindow) & 3], tot[(q + kWindow) & 3], lane, span[(q + kWindow) & 3]);
   }
   const u32 wave_tot = wave_running_sums(v, lane);
   stamp(3);
