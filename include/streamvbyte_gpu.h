@@ -306,6 +306,23 @@ int svbgpu_intersect_streams(int variant_a, const uint8_t *d_a, uint32_t count_a
                              size_t workspace_bytes, void *stream);
 
 /*
+ * Many pairs of delta-coded lists intersected in one launch (a query batch against an inverted
+ * index).  Pair i: list A_i = d_counts_a[i] values coded at d_bytes_a + d_byte_off_a[i], seed
+ * d_prevs_a[i] (0 for all when d_prevs_a is NULL); list B_i likewise.  The values of A_i that occur in
+ * B_i go, in A_i's order, to d_out + d_out_off[i] (room for d_counts_a[i] values), their number to
+ * d_n_out[i].  Every B_i must ascend without wrapping past 2^32; an A_i that steps back is answered
+ * correctly but makes its wavefront walk B_i again.  Both byte buffers readable STREAMVBYTE_PADDING
+ * bytes past their last stream.  One wavefront per pair: meant for lists of up to some tens of
+ * thousands of values (svbgpu_intersect_streams is the call for two long lists).  No workspace.  No
+ * counterpart in the reference.
+ */
+int svbgpu_intersect_batch(int variant, const uint8_t *d_bytes_a, const uint64_t *d_byte_off_a,
+                           const uint32_t *d_counts_a, const uint32_t *d_prevs_a,
+                           const uint8_t *d_bytes_b, const uint64_t *d_byte_off_b,
+                           const uint32_t *d_counts_b, const uint32_t *d_prevs_b, uint32_t npairs,
+                           uint32_t *d_out, const uint64_t *d_out_off, uint32_t *d_n_out, void *stream);
+
+/*
  * 64-bit values ("1248").  No counterpart in the reference, whose values are
  * uint32_t (include/streamvbyte.h:23 there); the container is the reference's:
  * (count + 3) / 4 control bytes, then the data bytes; four 2-bit codes per

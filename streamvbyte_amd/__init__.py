@@ -380,6 +380,22 @@ class DeviceCodec:
                                                      self._stream()), "svbgpu_intersect_streams")
         return out, self.res[4:5]
 
+    def intersect_batch(self, bytes_a, byte_off_a, counts_a, prevs_a, bytes_b, byte_off_b, counts_b, prevs_b,
+                        out, out_off, variant=V1234, n_out=None):
+        """Pairs of delta-coded lists (device tensors: uint8 bytes, int64 offsets, int32 counts, int32 seeds or
+        None) -> (out, n_out int32[npairs]): pair i's common values at out[out_off[i]:], in A_i's order."""
+        torch = self.torch
+        npairs = counts_a.numel()
+        if n_out is None:
+            n_out = torch.empty(max(npairs, 1), dtype=torch.int32, device=self.device)
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_intersect_batch(variant, ptr(bytes_a), ptr(byte_off_a), ptr(counts_a), ptr(prevs_a),
+                                                   ptr(bytes_b), ptr(byte_off_b), ptr(counts_b), ptr(prevs_b), npairs,
+                                                   ptr(out), ptr(out_off), ptr(n_out), self._stream()),
+                   "svbgpu_intersect_batch")
+        return out, n_out[:npairs]
+
     def decode_plan(self, stream, count, variant=V1234):
         with self.torch.cuda.device(self.device):
             _check(self.lib.svbgpu_decode_plan(variant, stream.data_ptr(), count, self.ws.data_ptr(),

@@ -1006,6 +1006,30 @@ int svbgpu_intersect_streams(int variant_a, const uint8_t* d_a, uint32_t count_a
   return SVBGPU_OK;
 }
 
+int svbgpu_intersect_batch(int variant, const uint8_t* d_bytes_a, const uint64_t* d_byte_off_a,
+                           const uint32_t* d_counts_a, const uint32_t* d_prevs_a, const uint8_t* d_bytes_b,
+                           const uint64_t* d_byte_off_b, const uint32_t* d_counts_b, const uint32_t* d_prevs_b,
+                           uint32_t npairs, uint32_t* d_out, const uint64_t* d_out_off, uint32_t* d_n_out,
+                           void* stream) {
+  if (bad_variant(variant)) return SVBGPU_EINVAL;
+  if (npairs == 0) return SVBGPU_OK;
+  if (!d_bytes_a || !d_byte_off_a || !d_counts_a || !d_bytes_b || !d_byte_off_b || !d_counts_b || !d_out ||
+      !d_out_off || !d_n_out)
+    return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  const unsigned grid = (npairs + kIsbWaves - 1) / kIsbWaves;
+  if (variant == SVBGPU_1234)
+    hipLaunchKernelGGL(k_intersect_batch<V1234>, dim3(grid), dim3(64 * kIsbWaves), 0, S(stream), d_bytes_a, d_byte_off_a,
+                       d_counts_a, d_prevs_a, d_bytes_b, d_byte_off_b, d_counts_b, d_prevs_b, npairs, d_out,
+                       d_out_off, d_n_out);
+  else
+    hipLaunchKernelGGL(k_intersect_batch<V0124>, dim3(grid), dim3(64 * kIsbWaves), 0, S(stream), d_bytes_a, d_byte_off_a,
+                       d_counts_a, d_prevs_a, d_bytes_b, d_byte_off_b, d_counts_b, d_prevs_b, npairs, d_out,
+                       d_out_off, d_n_out);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
 int svbgpu_encode64(unsigned flags, const uint64_t* d_in, uint32_t count, uint8_t* d_out, uint64_t prev, void* ws,
                     size_t ws_bytes, uint64_t* d_written, void* stream) {
   if (bad_flags(flags)) return SVBGPU_EINVAL;

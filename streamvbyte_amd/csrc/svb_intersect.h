@@ -362,6 +362,98 @@ __device__ __forceinline__ u32 wave_bound_fn(F f, u32 n, u32 key, int lane) {
   return lo;
 }
 
+// Which of the wave's values v[Q][4] (nints[q] of them valid per wave tile, all within [vmin, vmax]) occur among
+// the values c[4] of one wave tile of an ascending stream B (absolute values, bn of them valid, t_last the last)?
+// Bit q*16 + j*4 + k of the result stands for value k of v[q][j].  buf: 1024 words of the wave's own LDS.
+template <int Q>
+__device__ __forceinline__ u32 probe_wavetile(const uint4 (&c)[4], u32 bn, u32 t_last, u32 vmin, u32 vmax,
+                                              const uint4 (&v)[Q][4], const u32 (&nints)[Q], u32* buf, int lane) {
+  static_assert(Q <= 2, "hit bits are kept in 32 bits");
+  const u32 t_first = (u32)__builtin_amdgcn_readfirstlane((int)c[0].x);
+  if (t_last < vmin || t_first > vmax) return 0u;  // wave-uniform
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // A bitmap of B's values (one LDS read per value of A) where the values to enter lie within 32768 of each
+  // other: the whole wave tile when it is that dense, else only its values inside the span of the wave's own.
+  u32 hits = 0;  // bit q*16 + j*4 + k
+  u32 inr = 0xFFFFu, first = t_first, last = t_last, below = 0;
+  const bool whole = t_last - t_first < 32768u;
+  if (whole) {
+    inr = valid4(bn, 0, lane) | (valid4(bn, 1, lane) << 4) | (valid4(bn, 2, lane) << 8) | (valid4(bn, 3, lane) << 12);
+  } else {
+    u32 fmax = 0, fmin_inv = 0;
+    inr = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 m = valid4(bn, j, lane);
+      const u32 x[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool valid = (m >> k) & 1u;
+        const bool in = valid && x[k] >= vmin && x[k] <= vmax;
+        below += (valid && x[k] < vmin) ? 1u : 0u;
+        if (in) {
+          inr |= 1u << (4 * j + k);
+          fmax = max(fmax, x[k]);
+          fmin_inv = max(fmin_inv, ~x[k]);
+        }
+      }
+    }
+    if (__ballot(inr != 0u) == 0ull) return 0u;  // wave-uniform: nothing of this tile can meet the wave's values
+    first = ~wave_max(fmin_inv);
+    last = wave_max(fmax);
+  }
+  if (last - first < 32768u) {
+    const u32 span = last - first;  // a value outside it (B not ascending) is dropped, never written out of bounds
+    const u32 nw = (span >> 5) + 1u;
+    for (u32 e = lane; e < nw; e += 64) buf[e] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 d0 = c[j].x - first, d1 = c[j].y - first, d2 = c[j].z - first, d3 = c[j].w - first;
+      if ((inr & (1u << (4 * j))) && d0 <= span) atomicOr(&buf[d0 >> 5], 1u << (d0 & 31u));
+      if ((inr & (2u << (4 * j))) && d1 <= span) atomicOr(&buf[d1 >> 5], 1u << (d1 & 31u));
+      if ((inr & (4u << (4 * j))) && d2 <= span) atomicOr(&buf[d2 >> 5], 1u << (d2 & 31u));
+      if ((inr & (8u << (4 * j))) && d3 <= span) atomicOr(&buf[d3 >> 5], 1u << (d3 & 31u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hits |= lds_bits4(buf, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 m = valid4(bn, j, lane);
+      uint4 x = c[j];
+      if (!(m & 1u)) x.x = 0xFFFFFFFFu;
+      if (!(m & 2u)) x.y = 0xFFFFFFFFu;
+      if (!(m & 4u)) x.z = 0xFFFFFFFFu;
+      if (!(m & 8u)) x.w = 0xFFFFFFFFu;
+      *reinterpret_cast<uint4*>(buf + 4 * (j * 64 + lane)) = x;  // value i of the wave tile at buf[i]
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // B ascends, so the values inside the span are buf[lo .. lo + len): search a window of the array that
+    // holds them -- a power of two of entries, moved down where it would reach past the array's end (what
+    // it then takes in below lo is smaller than every candidate and sorted with the rest)
+    const u32 lo = wave_sum(below), len = wave_sum((u32)__popc(inr));
+    const u32 top = len > 1u ? 1u << (31 - __builtin_clz(len - 1u)) : 0u;
+    const u32 win = top ? 2u * top : 1u;
+    const u32 wb = min(lo, (u32)kWtInts - win);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hits |= lds_find4(buf + wb, win, top, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
+  }
+  __builtin_amdgcn_wave_barrier();
+  return hits;
+}
+
 // range[w] = the wave tiles [x, y) of stream B that wavefront w of k_stream_intersect (wave tiles kSxQ w ..
 // of stream A) can meet if A ascends there: from the tile ahead of the first whose preceding value is >= the
 // value preceding the wave's first, to the last whose preceding value is <= the wave's last value (= the
@@ -530,88 +622,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_stream_intersect(
       run += wave_last(incl);
       x.x += ex; x.y += ex; x.z += ex; x.w += ex;
     }
-    const u32 t_first = (u32)__builtin_amdgcn_readfirstlane((int)c[0].x);
-    const u32 t_last = run;  // absent values are zero deltas: the running sum ends on the last value
-    if (t_last < vmin || t_first > vmax) continue;  // wave-uniform
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // A bitmap of B's values (one LDS read per value of A) where the values to enter lie within 32768 of each
-    // other: the whole wave tile when it is that dense, else only its values inside the span of the wave's own.
-    u32 inr = 0xFFFFu, first = t_first, last = t_last, below = 0;
-    const bool whole = t_last - t_first < 32768u;
-    if (whole) {
-      inr = valid4(bn, 0, lane) | (valid4(bn, 1, lane) << 4) | (valid4(bn, 2, lane) << 8) | (valid4(bn, 3, lane) << 12);
-    } else {
-      u32 fmax = 0, fmin_inv = 0;
-      inr = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32 m = valid4(bn, j, lane);
-        const u32 x[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool valid = (m >> k) & 1u;
-          const bool in = valid && x[k] >= vmin && x[k] <= vmax;
-          below += (valid && x[k] < vmin) ? 1u : 0u;
-          if (in) {
-            inr |= 1u << (4 * j + k);
-            fmax = max(fmax, x[k]);
-            fmin_inv = max(fmin_inv, ~x[k]);
-          }
-        }
-      }
-      if (__ballot(inr != 0u) == 0ull) continue;  // wave-uniform: nothing of this tile can meet the wave's values
-      first = ~wave_max(fmin_inv);
-      last = wave_max(fmax);
-    }
-    if (last - first < 32768u) {
-      const u32 span = last - first;  // a value outside it (B not ascending) is dropped, never written out of bounds
-      const u32 nw = (span >> 5) + 1u;
-      for (u32 e = lane; e < nw; e += 64) buf[e] = 0u;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32 d0 = c[j].x - first, d1 = c[j].y - first, d2 = c[j].z - first, d3 = c[j].w - first;
-        if ((inr & (1u << (4 * j))) && d0 <= span) atomicOr(&buf[d0 >> 5], 1u << (d0 & 31u));
-        if ((inr & (2u << (4 * j))) && d1 <= span) atomicOr(&buf[d1 >> 5], 1u << (d1 & 31u));
-        if ((inr & (4u << (4 * j))) && d2 <= span) atomicOr(&buf[d2 >> 5], 1u << (d2 & 31u));
-        if ((inr & (8u << (4 * j))) && d3 <= span) atomicOr(&buf[d3 >> 5], 1u << (d3 & 31u));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < kSxQ; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          hits |= lds_bits4(buf, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32 m = valid4(bn, j, lane);
-        uint4 x = c[j];
-        if (!(m & 1u)) x.x = 0xFFFFFFFFu;
-        if (!(m & 2u)) x.y = 0xFFFFFFFFu;
-        if (!(m & 4u)) x.z = 0xFFFFFFFFu;
-        if (!(m & 8u)) x.w = 0xFFFFFFFFu;
-        *reinterpret_cast<uint4*>(buf + 4 * (j * 64 + lane)) = x;  // value i of the wave tile at buf[i]
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // B ascends, so the values inside the span are buf[lo .. lo + len): search a window of the array that
-      // holds them -- a power of two of entries, moved down where it would reach past the array's end (what
-      // it then takes in below lo is smaller than every candidate and sorted with the rest)
-      const u32 lo = wave_sum(below), len = wave_sum((u32)__popc(inr));
-      const u32 top = len > 1u ? 1u << (31 - __builtin_clz(len - 1u)) : 0u;
-      const u32 win = top ? 2u * top : 1u;
-      const u32 wb = min(lo, (u32)kWtInts - win);
-#pragma unroll
-      for (int q = 0; q < kSxQ; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          hits |= lds_find4(buf + wb, win, top, first, last, v[q][j], valid4(nints[q], j, lane)) << (q * 16 + j * 4);
-    }
-    __builtin_amdgcn_wave_barrier();
+    hits |= probe_wavetile<kSxQ>(c, bn, run, vmin, vmax, v, nints, buf, lane);  // run: B's last value so far
   }
 
   // ---- the tile's place in the output ----
@@ -647,6 +658,126 @@ __global__ __launch_bounds__(NW * 64, 4) void k_stream_intersect(
       if (m & 4u) *p++ = r.z;
       if (m & 8u) *p++ = r.w;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Many pairs of delta-coded lists intersected in one launch: a wavefront per pair, no directory, no
+// look-back (pair i writes its hits to a place of its own).  The wave walks list A 2048 values at a time
+// (data offset and running sum carried in registers, as the batched decoder does) and, for each such
+// piece, list B one wave tile at a time from the first tile that reached the previous piece, up to the
+// first whose preceding value lies beyond the piece.  B must ascend; an A that steps back makes the wave
+// start B over.  Results equal svbgpu_intersect_streams pair by pair.
+#ifndef SVB_ISB_WAVES
+#define SVB_ISB_WAVES 1
+#endif
+constexpr int kIsbWaves = SVB_ISB_WAVES;  // pairs (= wavefronts) per workgroup
+template <int V>
+__global__ __launch_bounds__(64 * kIsbWaves) void k_intersect_batch(
+    const u8* __restrict__ a_bytes, const u64* __restrict__ a_off, const u32* __restrict__ a_counts,
+    const u32* __restrict__ a_prevs, const u8* __restrict__ b_bytes, const u64* __restrict__ b_off,
+    const u32* __restrict__ b_counts, const u32* __restrict__ b_prevs, u32 npairs, u32* __restrict__ out,
+    const u64* __restrict__ out_off, u32* __restrict__ n_out) {
+  __shared__ WaveLds s_lds[kIsbWaves];
+  const int lane = lane_id(), wave = wave_id();
+  const u32 pair = blockIdx.x * kIsbWaves + wave;
+  if (pair >= npairs) return;  // wave-uniform; no workgroup barrier below
+  WaveLds& S = s_lds[wave];
+  u32* buf = reinterpret_cast<u32*>(S.data);
+  const u32 a_count = a_counts[pair], b_count = b_counts[pair];
+  const u8* a_in = a_bytes + a_off[pair];
+  const u8* b_in = b_bytes + b_off[pair];
+  u32* dst = out + out_off[pair];
+  const u32 a_keylen = (u32)(((u64)a_count + 3) >> 2), b_keylen = (u32)(((u64)b_count + 3) >> 2);
+  const u32 a_nwt = (a_keylen + kWtKeys - 1) / kWtKeys, b_nwt = (b_keylen + kWtKeys - 1) / kWtKeys;
+  auto load_keys = [&](const u8* in, u32 keylen, u32 wt) -> u32 {  // the wave tile's keys; past the stream's keys: its last
+    const u32 left = keylen - wt * (u32)kWtKeys;                    // >= 1
+    return ld_u32(in + (u64)wt * kWtKeys + min(4u * (u32)lane, (left - 1u) & ~3u));
+  };
+  auto integrate = [&](uint4 (&c)[4], u32& run) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4& x = c[j];
+      x.y += x.x; x.z += x.y; x.w += x.z;
+      const u32 incl = wave_scan_incl(x.w, lane);
+      const u32 ex = incl - x.w + run;
+      run += wave_last(incl);
+      x.x += ex; x.y += ex; x.z += ex; x.w += ex;
+    }
+  };
+  // where B's walk starts for the next piece of A: a wave tile, its data offset, the value preceding it
+  const u32 b_seed = b_prevs ? b_prevs[pair] : 0u;
+  u32 rs_t = 0, rs_before = b_seed;
+  u64 rs_doff = 0;
+  u32 a_run = a_prevs ? a_prevs[pair] : 0u;
+  u64 a_doff = 0;
+  u32 total_hits = 0;
+  for (u32 wt0 = 0; wt0 < a_nwt; wt0 += kSxQ) {
+    uint4 v[kSxQ][4];
+    u32 nints[kSxQ];
+#pragma unroll
+    for (int q = 0; q < kSxQ; ++q) {
+      const u32 wt = wt0 + q;
+      nints[q] = wt < a_nwt ? min((u32)kWtInts, a_count - wt * (u32)kWtInts) : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[q][j] = make_uint4(0, 0, 0, 0);
+      if (nints[q]) {
+        const u32 w = load_keys(a_in, a_keylen, wt);
+        a_doff += decode_wavetile<V, false>(w, nints[q], a_in + a_keylen + a_doff, lane, S, v[q]);
+        integrate(v[q], a_run);
+      }
+    }
+    u32 vmax = 0, vmin_inv = 0;
+#pragma unroll
+    for (int q = 0; q < kSxQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 m = valid4(nints[q], j, lane);
+        const uint4& c = v[q][j];
+        if (m & 1u) { vmax = max(vmax, c.x); vmin_inv = max(vmin_inv, ~c.x); }
+        if (m & 2u) { vmax = max(vmax, c.y); vmin_inv = max(vmin_inv, ~c.y); }
+        if (m & 4u) { vmax = max(vmax, c.z); vmin_inv = max(vmin_inv, ~c.z); }
+        if (m & 8u) { vmax = max(vmax, c.w); vmin_inv = max(vmin_inv, ~c.w); }
+      }
+    vmax = wave_max(vmax);
+    const u32 vmin = ~wave_max(vmin_inv);
+    // every tile before rs_t ends at or below rs_before: it can be skipped only if that lies below vmin
+    if (rs_t && vmin <= rs_before) { rs_t = 0; rs_before = b_seed; rs_doff = 0; }
+    u32 t = rs_t, run = rs_before;
+    u64 doff = rs_doff;
+    bool kept = false;
+    u32 hits = 0;
+    while (t < b_nwt && run <= vmax) {  // run = the value preceding tile t: nothing from t on is below it
+      const u32 before = run;
+      const u64 doff0 = doff;
+      const u32 bn = min((u32)kWtInts, b_count - t * (u32)kWtInts);
+      uint4 c[4];
+      const u32 w = load_keys(b_in, b_keylen, t);
+      doff += decode_wavetile<V, false>(w, bn, b_in + b_keylen + doff, lane, S, c);
+      integrate(c, run);
+      if (run >= vmin) {
+        if (!kept) { kept = true; rs_t = t; rs_before = before; rs_doff = doff0; }
+        hits |= probe_wavetile<kSxQ>(c, bn, run, vmin, vmax, v, nints, buf, lane);
+      }
+      ++t;
+    }
+    if (!kept) { rs_t = t; rs_before = run; rs_doff = doff; }  // everything walked lies below this piece
+#pragma unroll
+    for (int q = 0; q < kSxQ; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 m = (hits >> (q * 16 + j * 4)) & 15u;
+        const u32 cnt = (u32)__popc(m);
+        const u32 incl = wave_scan_incl(cnt, lane);
+        u32* p = dst + total_hits + (incl - cnt);
+        total_hits += wave_last(incl);
+        const uint4& r = v[q][j];
+        if (m & 1u) *p++ = r.x;
+        if (m & 2u) *p++ = r.y;
+        if (m & 4u) *p++ = r.z;
+        if (m & 8u) *p++ = r.w;
+      }
+  }
+  if (lane == 0) n_out[pair] = total_hits;
 }
 
 }  // namespace svb

@@ -677,6 +677,65 @@ def test_intersect_streams(torch_mod, codec, oracle, variant_a, variant_b):
 
 
 @pytest.mark.parametrize("variant", [V1234, V0124])
+def test_intersect_batch(torch_mod, codec, oracle, variant):
+    """svbgpu_intersect_batch pair by pair = the oracle's decode of both lists, then numpy isin: empty lists,
+    lists of one value, of exactly one and two wave tiles, long ones, B far denser / sparser than A, B wholly
+    below or above A, seeds, repeats, and a few A that step back (B must ascend, A need not)."""
+    torch = torch_mod
+    rng = np.random.default_rng(300 + variant)
+    sizes = [0, 1, 3, 1024, 1025, 2048, 2049, 4096, 5000, 20000, 70000]
+    pairs = []
+    for i in range(160):
+        na = int(rng.choice(sizes)) if rng.random() < 0.4 else int(rng.integers(0, 6000))
+        nb = int(rng.choice(sizes)) if rng.random() < 0.4 else int(rng.integers(0, 6000))
+        gap_a = int(rng.choice([2, 30, 400, 70000]))
+        gap_b = int(rng.choice([2, 30, 400, 70000]))
+        pa = int(rng.integers(0, 1 << 20)) if rng.random() < 0.3 else 0
+        pb = int(rng.integers(0, 1 << 20)) if rng.random() < 0.3 else 0
+        a = (np.cumsum(rng.integers(0, gap_a, na, dtype=np.uint64)) + pa).astype(np.uint32)
+        b = (np.cumsum(rng.integers(0, gap_b, nb, dtype=np.uint64)) + pb)
+        b = b[b < (1 << 32)].astype(np.uint32)
+        kind = i % 8
+        if kind == 0 and na > 10:                      # A steps back in the middle
+            a = np.concatenate([a[na // 2:], a[: na // 2]])
+        elif kind == 1 and nb:                         # B wholly above A
+            b = np.unique((b.astype(np.uint64) + (int(a.max()) + 5 if na else 0)) % (1 << 32)).astype(np.uint32)
+            pb = 0
+        elif kind == 2 and na and nb:                  # some of A's own values in B for sure
+            b = np.unique(np.concatenate([b, a[:: 7]]))
+            pb = 0
+        if b.size and pb > int(b[0]):
+            pb = int(b[0])
+        pairs.append((a, pa, np.sort(b), pb))
+    sa = [oracle.encode(variant, a, True, pa) if a.size else np.zeros(0, np.uint8) for a, pa, _, _ in pairs]
+    sb = [oracle.encode(variant, b, True, pb) if b.size else np.zeros(0, np.uint8) for _, _, b, pb in pairs]
+
+    def pack(streams):
+        off = np.zeros(len(streams) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([x.size for x in streams])
+        return dev_stream(torch, np.concatenate(streams)), torch.from_numpy(off[:-1].copy()).cuda()
+    bytes_a, off_a = pack(sa)
+    bytes_b, off_b = pack(sb)
+    counts_a = torch.tensor([p[0].size for p in pairs], dtype=torch.int32, device="cuda:0")
+    counts_b = torch.tensor([p[2].size for p in pairs], dtype=torch.int32, device="cuda:0")
+    prevs_a = to_dev(torch, np.array([p[1] for p in pairs], dtype=np.uint32))
+    prevs_b = to_dev(torch, np.array([p[3] for p in pairs], dtype=np.uint32))
+    out_off = np.zeros(len(pairs) + 1, dtype=np.int64)
+    out_off[1:] = np.cumsum([p[0].size for p in pairs])
+    out = torch.full((int(out_off[-1]) + 1,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+    _, n_out = codec.intersect_batch(bytes_a, off_a, counts_a, prevs_a, bytes_b, off_b, counts_b, prevs_b, out,
+                                     torch.from_numpy(out_off[:-1].copy()).cuda(), variant=variant)
+    got_n = n_out.cpu().numpy()
+    got = to_np(out, np.uint32)
+    for i, (a, pa, b, pb) in enumerate(pairs):
+        expect = a[np.isin(a, b)]
+        assert got_n[i] == expect.size, (i, a.size, b.size)
+        assert np.array_equal(got[out_off[i]: out_off[i] + expect.size], expect), (i, a.size, b.size)
+        # nothing written past the pair's hits
+        assert np.all(got[out_off[i] + expect.size: out_off[i + 1]] == 0x5A5A5A5A), (i,)
+
+
+@pytest.mark.parametrize("variant", [V1234, V0124])
 def test_validate_batch(torch_mod, codec, oracle, variant):
     """svbgpu_validate_batch = the oracle's validate_stream stream by stream, for right and wrong lengths,
     empty streams, lengths below the key bytes and tampered keys."""
