@@ -134,6 +134,19 @@ if want("misc"):
     ops["zigzag_enc"] = (lambda: codec.zigzag(values, "encode", out=out), 8.0 * n)
     tmpz = torch.empty(n, dtype=torch.int32, device=dev)
     ops["zigzag_delta_dec"] = (lambda: codec.zigzag(values, "delta_decode", out=tmpz), 8.0 * n)
+if want("intersect"):
+    # dense postings against every 8th of their own values: as a sorted array, and as a delta-coded stream
+    gi = torch.Generator(device=dev); gi.manual_seed(5)
+    pst = torch.cumsum(torch.randint(0, 32 if n <= (1 << 27) else 16, (n,), generator=gi, device=dev, dtype=torch.int64), 0)
+    pst = torch.where(pst >= (1 << 31), pst - (1 << 32), pst).to(torch.int32)
+    si, zi = codec.encode(pst, flags=svb.DELTA)
+    si = si[: int(zi.item()) + 16].clone()
+    bi = pst[::8].contiguous()
+    sbi, zbi = codec.encode(bi, flags=svb.DELTA)
+    sbi = sbi[: int(zbi.item()) + 16].clone()
+    hits_i = torch.empty(n, dtype=torch.int32, device=dev)
+    ops["intersect_array"] = (lambda: codec.decode_intersect(si, n, bi, out=hits_i), int(zi.item()) + 4.0 * bi.numel() + 4.0 * bi.numel())
+    ops["intersect_streams"] = (lambda: codec.intersect_streams(si, n, sbi, bi.numel(), out=hits_i), int(zi.item()) + int(zbi.item()) + 4.0 * bi.numel())
 if want("wide"):
     n8 = min(n, 1 << 27)
     g = torch.Generator(device=dev); g.manual_seed(11)
