@@ -388,6 +388,15 @@ int svbgpu_decode_batch(int variant, unsigned flags, const uint8_t *d_bytes,
                         const uint32_t *d_counts, const uint32_t *d_prev, uint32_t nstreams,
                         uint64_t *d_sizes, void *stream);
 
+/* streamvbyte_compressedbytes / _0124 (reference include/streamvbyte.h:47,55) for every stream of a
+ * batch: d_sizes[s] = the exact number of bytes svbgpu_encode_batch with the same arguments writes for
+ * stream s, so that a caller can place the streams back to back before encoding them (an exclusive
+ * scan of d_sizes gives d_byte_off).  Reads 4 bytes per value, writes nothing else. */
+int svbgpu_compressedbytes_batch(int variant, unsigned flags, const uint32_t *d_values,
+                                 const uint64_t *d_value_off, const uint32_t *d_counts,
+                                 const uint32_t *d_prev, uint32_t nstreams, uint64_t *d_sizes,
+                                 void *stream);
+
 /* streamvbyte_validate_stream / _0124 (reference include/streamvbyte.h:75,79)
  * for every stream of a batch: d_ok[s] = 1 when the first d_counts[s] codes of
  * the stream at d_bytes + d_byte_off[s] promise exactly d_lengths[s] bytes of

@@ -456,6 +456,20 @@ class DeviceCodec:
                                                 sizes.data_ptr(), self._stream()), "svbgpu_encode_batch")
         return sizes
 
+    def compressedbytes_batch(self, values, value_off, counts, prevs=None, variant=V1234, flags=0, sizes=None):
+        """Exact encoded size of every stream of a batch (int64 tensor), without encoding."""
+        torch = self.torch
+        ns = counts.numel()
+        if sizes is None:
+            sizes = torch.empty(ns, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.svbgpu_compressedbytes_batch(variant, flags, values.data_ptr(), value_off.data_ptr(),
+                                                         counts.data_ptr(),
+                                                         prevs.data_ptr() if prevs is not None else None, ns,
+                                                         sizes.data_ptr(), self._stream()),
+                   "svbgpu_compressedbytes_batch")
+        return sizes
+
     def decode_batch(self, byte_buf, byte_off, values, value_off, counts, prevs=None, variant=V1234, flags=0,
                      sizes=None):
         torch = self.torch

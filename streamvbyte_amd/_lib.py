@@ -55,6 +55,7 @@ SIGNATURES = {
     "svbgpu_intersect_workspace_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "svbgpu_intersect_streams": (C.c_int, [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.c_uint32, C.c_uint32,
                                            vp, vp, vp, C.c_size_t, vp]),
+    "svbgpu_compressedbytes_batch": (C.c_int, [C.c_int, C.c_uint, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "svbgpu_intersect_batch": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp]),
     "svbgpu_compressedbytes": (C.c_int, [C.c_int, C.c_uint, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "svbgpu_validate": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_size_t, vp]),

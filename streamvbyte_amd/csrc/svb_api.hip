@@ -486,6 +486,12 @@ void launch_size(const uint32_t* d_in, uint32_t count, uint32_t prev, uint64_t* 
                    hipLaunchKernelGGL((k_size<V, D, Z, NTV>), dim3(grid), dim3(kBlock), 0, st, d_in, count, prev, d_bytes))
 }
 
+template <int V, bool D, bool Z>
+void launch_size_batch(const uint32_t* d_values, const uint64_t* d_value_off, const uint32_t* d_counts,
+                       const uint32_t* d_prev, uint32_t nstreams, uint64_t* d_sizes, hipStream_t st) {
+  hipLaunchKernelGGL((k_size_batch<V, D, Z>), dim3((nstreams + kWaves - 1) / kWaves), dim3(kBlock), 0, st, d_values,
+                     d_value_off, d_counts, d_prev, nstreams, d_sizes);
+}
 #define DISPATCH_VDZ(fn, variant, flags, ...)                                              \
   do {                                                                                     \
     const bool d_ = (flags)&SVBGPU_DELTA, z_ = (flags)&SVBGPU_ZIGZAG;                      \
@@ -1125,6 +1131,18 @@ int svbgpu_validate_batch(int variant, const uint8_t* d_bytes, const uint64_t* d
   else
     hipLaunchKernelGGL((k_validate_lists<V0124, u64, true>), dim3(grid), dim3(kBlock), 0, S(stream), d_bytes, d_byte_off,
                        d_counts, d_lengths, nstreams, d_ok);
+  HIP_TRY(hipGetLastError());
+  return SVBGPU_OK;
+}
+
+int svbgpu_compressedbytes_batch(int variant, unsigned flags, const uint32_t* d_values, const uint64_t* d_value_off,
+                                 const uint32_t* d_counts, const uint32_t* d_prev, uint32_t nstreams,
+                                 uint64_t* d_sizes, void* stream) {
+  if (bad_variant(variant) || bad_flags(flags)) return SVBGPU_EINVAL;
+  if (nstreams == 0) return SVBGPU_OK;
+  if (!d_values || !d_value_off || !d_counts || !d_sizes) return SVBGPU_EINVAL;
+  if (!dev_info().ok) return SVBGPU_ENODEVICE;
+  DISPATCH_VDZ(launch_size_batch, variant, flags, d_values, d_value_off, d_counts, d_prev, nstreams, d_sizes, S(stream));
   HIP_TRY(hipGetLastError());
   return SVBGPU_OK;
 }

@@ -80,6 +80,45 @@ __global__ __launch_bounds__(kBlock) void k_size(const u32* __restrict__ in, u32
 }
 
 // ---------------------------------------------------------------------------
+// k_size_batch: k_size for every stream of a batch -- sizes[s] = the bytes streamvbyte_compressedbytes
+// (reference src/streamvbyte_encode.c:91-108) gives for stream s, whose counts[s] values start at
+// values + value_off[s].  A wavefront per stream; values come in 16-byte loads (a stream may start at
+// any uint32), the last one to three singly.  With DELTA the widths are those of the differences, the
+// first against prevs[s] (0 when prevs is null).
+template <int V, bool DELTA, bool ZZ>
+__global__ __launch_bounds__(kBlock) void k_size_batch(const u32* __restrict__ values, const u64* __restrict__ value_off,
+                                                       const u32* __restrict__ counts, const u32* __restrict__ prevs,
+                                                       u32 nstreams, u64* __restrict__ sizes) {
+  const int lane = lane_id();
+  const u32 s = blockIdx.x * kWaves + wave_id();
+  if (s >= nstreams) return;
+  const u32 count = counts[s];
+  const u32* in = values + value_off[s];
+  const u32 prev = (DELTA && prevs) ? prevs[s] : 0u;
+  const u32 nquads = count >> 2;
+  u32 acc = 0;  // at most 4 bytes for each of < 2^32 values, 64 lanes: a lane's share fits 32 bits
+  for (u32 q = lane; q < nquads; q += 64) {
+    const uint4 x = ld_stream16<false>(in + 4ull * q);
+    u32 v[4] = {x.x, x.y, x.z, x.w};
+    if (DELTA) {
+      const u32 p = q ? in[4ull * q - 1] : prev;
+      const u32 d0 = v[0] - p, d1 = v[1] - v[0], d2 = v[2] - v[1], d3 = v[3] - v[2];
+      v[0] = d0; v[1] = d1; v[2] = d2; v[3] = d3;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += len_of<V>(code_of<V>(ZZ ? zz_enc(v[k]) : v[k]));
+  }
+  if ((u32)lane < (count & 3u)) {
+    const u64 i = ((u64)nquads << 2) + lane;
+    u32 v = in[i];
+    if (DELTA) v -= i ? in[i - 1] : prev;
+    acc += len_of<V>(code_of<V>(ZZ ? zz_enc(v) : v));
+  }
+  const u64 tot = wave_sum64((u64)acc);
+  if (lane == 0) sizes[s] = tot + (((u64)count + 3) >> 2);
+}
+
+// ---------------------------------------------------------------------------
 // k_validate_sum: data bytes promised by the first `count` codes of the key
 // block (reference src/streamvbyte_decode.c:113-133,
 // src/streamvbyte_0124_decode.c:206-226) and, in the workgroup that finishes

@@ -271,6 +271,9 @@ def test_batched_streams(torch_mod, codec, oracle):
             expect = oracle.encode(variant, v, bool(flags & DELTA), int(prevs[s]))
             assert h_sizes[s] == expect.size, (s, counts[s])
             assert np.array_equal(h_buf[int(boff[s]): int(boff[s]) + expect.size], expect), (s, counts[s])
+        # the size pre-pass of the batch (streamvbyte_compressedbytes stream by stream) agrees without encoding
+        cb = codec.compressedbytes_batch(d_values, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+        assert np.array_equal(cb.cpu().numpy(), h_sizes)
         back = torch.zeros_like(d_values)
         used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
         assert np.array_equal(used.cpu().numpy(), h_sizes)
@@ -338,6 +341,15 @@ def test_batched_flag_combinations(torch_mod, codec, oracle, variant, flagbits):
         expect = _expected_stream(oracle, variant, flags, v, int(prevs[s]) if flags & DELTA else 0)
         assert h_sizes[s] == expect.size, (s, counts[s])
         assert np.array_equal(h_buf[int(boff[s]): int(boff[s]) + expect.size], expect), (s, counts[s])
+    cb = codec.compressedbytes_batch(d_values, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+    assert np.array_equal(cb.cpu().numpy(), h_sizes)
+    cb = codec.compressedbytes_batch(d_values, d_voff, d_counts, None, variant=variant, flags=flags)   # seeds default to 0
+    if flags & DELTA:
+        for s in range(0, ns, 7):
+            v = values[int(voff[s]): int(voff[s + 1])]
+            assert int(cb[s].item()) == _expected_stream(oracle, variant, flags, v, 0).size, (s,)
+    else:
+        assert np.array_equal(cb.cpu().numpy(), h_sizes)
     back = torch.zeros_like(d_values)
     used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
     assert np.array_equal(used.cpu().numpy(), h_sizes)
