@@ -61,6 +61,61 @@ __global__ __launch_bounds__(256, 7) void k_copy(const u32x4* __restrict__ src, 
   }
 }
 
+// mode 3: a fresh workgroup per 4 * per_wave pieces (each wave per_wave consecutive pieces), dispatched in order
+// mode 4: persistent workgroups that draw the next 4 consecutive pieces from an atomic ticket
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256, 7) void k_copy2(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int per_wave,
+                                                  unsigned total_groups, unsigned* ticket) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto ld = [&](const u32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; };
+  auto st = [&](u32x4* p, u32x4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; };
+  auto piece = [&](size_t idx) {
+    const u32x4* sp = src + idx * 256 + lane;
+    u32x4* dp = dst + idx * 256 + lane;
+    u32x4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = ld(sp + j * 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j].x ^= 1u; st(dp + j * 64, r[j]); }
+  };
+  if (MODE == 3) {
+    for (int i = 0; i < per_wave; ++i) piece(((size_t)blockIdx.x * 4 + wave) * per_wave + i);
+  } else {
+    __shared__ unsigned s_t;
+    for (;;) {
+      if (threadIdx.x == 0) s_t = atomicAdd(ticket, 1u);
+      __syncthreads();
+      const unsigned t = s_t;
+      __syncthreads();
+      if (t >= total_groups) break;
+      piece((size_t)t * 4 + wave);
+    }
+  }
+}
+
+template <int MODE, bool NT>
+static void run2(const char* name, const u32x4* src, u32x4* dst, size_t pieces, int per_wave, unsigned* ticket) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const unsigned groups = (unsigned)(pieces / 4);
+  const unsigned grid = MODE == 3 ? (unsigned)(pieces / 4 / per_wave) : 256 * 7;
+  const int reps = 10;
+  float tot = 0;
+  for (int r = 0; r < reps + 2; ++r) {
+    (void)hipMemsetAsync(ticket, 0, 4, 0);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k_copy2<MODE, NT>), dim3(grid), dim3(256), 0, 0, src, dst, per_wave, groups, ticket);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (r >= 2) tot += ms;
+  }
+  const float ms = tot / reps;
+  printf("%-44s %8.4f ms  %7.1f GB/s (read + write)\n", name, ms, 2.0 * pieces * 4096.0 / ms / 1e6);
+}
+
 template <int MODE, bool NT>
 static void run(const char* name, const u32x4* src, u32x4* dst, int blocks, int iters) {
   hipEvent_t e0, e1;
@@ -92,6 +147,15 @@ int main() {
     run<2, true>("  pieces dealt round-robin (non-temporal)", src, dst, blocks, iters);
     run<0, true>("  store, then load the next (non-temporal)", src, dst, blocks, iters);
     run<1, true>("  load the next, then store (non-temporal)", src, dst, blocks, iters);
+    unsigned* ticket;
+    if (hipMalloc(&ticket, 256) != hipSuccess) return 1;
+    const size_t pieces = n16 / 256;
+    run2<3, true>("  fresh workgroups, 1 piece per wave (nt)", src, dst, pieces, 1, ticket);
+    run2<3, true>("  fresh workgroups, 4 pieces per wave (nt)", src, dst, pieces, 4, ticket);
+    run2<3, false>("  fresh workgroups, 1 piece per wave", src, dst, pieces, 1, ticket);
+    run2<4, true>("  persistent, pieces by ticket (nt)", src, dst, pieces, 1, ticket);
+    run2<4, false>("  persistent, pieces by ticket", src, dst, pieces, 1, ticket);
+    (void)hipFree(ticket);
     (void)hipFree(src); (void)hipFree(dst);
   }
   return 0;
