@@ -65,13 +65,18 @@ int svbgpu_build_has(const char *feature);
 /* Tuning knobs.  Each is an atomic word; every API call reads all of them once
  * on entry and works from that snapshot, so a change never reaches a call that
  * is already running and may be made from any thread.
- *   "encode_pipeline" = 0|1|2   1 (default): plain and zigzag encodes run the
- *                               software-pipelined kernel (a tile's loads and
- *                               look-back overlap the previous tile's stores),
- *                               differential encodes one tile at a time; 0: every
- *                               encode one tile at a time; 2: differential encodes
- *                               pipelined too (10 % faster on gaps of mixed width,
- *                               12 % slower on dense postings of one byte a gap)
+ *   "encode_pipeline" = 0|1|2|3 3 (default): the encoder is chosen by the stream's
+ *                               size (short streams and plain input of 2^25..2^27
+ *                               values the software-pipelined kernel, in which a
+ *                               tile's loads and look-back overlap the previous
+ *                               tile's stores; the rest one tile at a time, a
+ *                               workgroup per tile); 0: every encode one tile at a
+ *                               time; 1: plain and zigzag encodes pipelined,
+ *                               differential ones not; 2: every encode pipelined
+ *   "encode_fresh" = 0|1        tile-at-a-time encoder: 1 (default) a workgroup per
+ *                               tile, 0 persistent workgroups that loop over tiles
+ *   "encode_waves" = 4|8|16     tile-at-a-time encoder when "encode_pipeline" is not
+ *                               3: waves per workgroup (a tile is 4096 values a wave)
  *   "encode_ticket_early" = -1|0|1  pipelined encoder: 1 asks for a tile's place in
  *                               the stream one store phase before the tile is
  *                               loaded, 0 when it is loaded; -1 (default): 1 for

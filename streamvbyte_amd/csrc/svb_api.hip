@@ -110,13 +110,14 @@ struct Options {
   int delta_lookback;    // 1: single-pass look-back differential decoder, 0: two streaming passes
   int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8)
   int encode64_waves;    // waves (= wave tiles) per workgroup of k_encode64_lb (4, 8 or 16)
+  int encode_fresh;      // k_encode as a workgroup per tile (1) or as persistent workgroups looping over tickets (0)
   int encode_qw;         // wave tiles per wave in k_encode (1, 2 or 4)
   int batch_lists_per_wave;  // row/wave batched kernels: lists per wave of a launch, 0 = one grid that fills the device
   int batch_chunk;       // batched calls: -1 chunked kernels, streams per wavefront chosen from the batch size;
                          // 1..64 chunked kernels with that many; 0 the row + wave kernel pair
   unsigned debug;        // timing-only ablations (wrong results!)
   int zigzag_piece;      // values per device scan of the host-pointer zigzag_delta_decode
-  int encode_pipeline;   // 1: k_encode_pipe (two half-size tiles in flight per workgroup), 0: k_encode
+  int encode_pipeline;   // 0: k_encode, 1: k_encode_pipe (two half-size tiles in flight per workgroup) for plain input, 2: always, 3: by size (choose_encoder)
   int encode_ticket_early;  // k_encode_pipe: 1 requests a tile's ticket one store phase before the tile is loaded
   int host_cpu_cutoff;   // host-pointer calls on fewer values than this run on the host codec (svb_cpu.h)
   int host_serialize;    // host-pointer calls: one at a time per device inside the runtime
@@ -126,8 +127,8 @@ struct Options {
   int nt_force;          // -1: by size; 0..3: this policy whatever the size (bit 0 loads, bit 1 stores)
   unsigned lb_tag2 = 0;  // not a knob: the look-back tag of the running call (LbWords::tag2), set by prepare_lookback
 };
-std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8}, o_encode64_waves{8},
-    o_encode_qw{4}, o_encode_pipeline{1}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
+std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8}, o_encode64_waves{8}, o_encode_fresh{1},
+    o_encode_qw{4}, o_encode_pipeline{3}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
     o_host_stage_pageable{1}, o_nt_threshold_mib{128}, o_nt_force{-1}, o_host_pointers_only{0};
 inline Options options() {
   Options o;
@@ -138,6 +139,7 @@ inline Options options() {
   o.delta_lookback = o_delta_lookback.load(rl);
   o.encode_waves = o_encode_waves.load(rl);
   o.encode64_waves = o_encode64_waves.load(rl);
+  o.encode_fresh = o_encode_fresh.load(rl);
   o.encode_qw = o_encode_qw.load(rl);
   o.encode_pipeline = o_encode_pipeline.load(rl);
   o.encode_ticket_early = o_encode_ticket_early.load(rl);
@@ -425,8 +427,12 @@ void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, ui
   // diagnostic stamps live behind the regular workspace when the caller over-allocated it
   u64* stamps = (o.debug & 16u) && ws_bytes >= L.total + 40ull * (full_tiles + 2)
                     ? ws_at<u64>(ws, L.total) : nullptr;
-  const unsigned grid = stream_grid(full_tiles, NW == 8 ? (QW <= 2 ? 3 : 2) : (QW > 2 || V != V1234 ? 4 : 5));
-  if (full_tiles && QW == 4)  // the shapes in regular use take the non-temporal policy of the call
+  const unsigned grid = stream_grid(full_tiles, NW == 16 ? 1 : NW == 8 ? (QW <= 2 ? 3 : 2) : (QW > 2 || V != V1234 ? 4 : 5));
+  if (full_tiles && QW == 4 && o.encode_fresh)  // a workgroup per tile
+    SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
+                      hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW, (QW == 4 ? NTV : 0)>), dim3(full_tiles), dim3(NW * 64), 0,
+                                         st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug | 8u, stamps))
+  else if (full_tiles && QW == 4)  // the shapes in regular use take the non-temporal policy of the call
     SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
                       hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW, (QW == 4 ? NTV : 0)>), dim3(grid), dim3(NW * 64), 0,
                                          st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps))
@@ -464,18 +470,33 @@ void launch_encode_pipe(const Options& o, const uint32_t* d_in, uint32_t count, 
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, 0u, (u64*)nullptr);
 }
+// Which encoder for a call.  encode_pipeline 0 / 1 / 2 force k_encode / k_encode_pipe for plain input /
+// k_encode_pipe always; 3 (the default) picks by size, from the steady-state sweep of
+// tools/encode_shape_sweep.py: short streams do best pipelined (half-size tiles: more of them to spread),
+// streams of 2^23 values with the tile-at-a-time kernel, a workgroup per tile; around 2^24 the 16-wave tile
+// (one round of tiles over the device); plain input up to 2^27 pipelined again; everything longer, and
+// differential input from 2^25 up, tile at a time with 8 waves and a workgroup per tile (2^28 values of mixed
+// widths: 0.667 of the HBM peak against 0.639 pipelined; dense postings 0.662 against 0.513).
+struct EncoderChoice { bool pipe; int waves; };
+inline EncoderChoice choose_encoder(const Options& o, bool delta, uint32_t count) {
+  if (o.encode_pipeline != 3) return {o.encode_pipeline == 2 || (o.encode_pipeline == 1 && !delta), o.encode_waves};
+  if (count < (1u << 23)) return {true, 8};
+  if (count < (1u << 24)) return {false, 8};
+  if (count < (1u << 25)) return {false, 16};
+  if (!delta && count < (1u << 27)) return {true, 8};
+  return {false, 8};
+}
 template <int V, bool D, bool Z>
 void launch_encode(const Options& o, const uint32_t* d_in, uint32_t count, uint8_t* d_out, uint32_t prev, void* ws,
                    size_t ws_bytes, uint64_t* d_written, hipStream_t st) {
-  // Differential coding keeps the larger tiles of k_encode: posting-list gaps are mostly one byte, the
-  // store phase is then short, and the pipelined kernel's twice as many tickets (one atomic on one word
-  // each, ~60 per microsecond at best) become the limit: dense postings 0.28 ms against 0.33 ms.
-  if (o.encode_pipeline && (!D || o.encode_pipeline == 2) && !(o.debug & ~(16u | 64u))) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  const EncoderChoice c = choose_encoder(o, D, count);
+  if (c.pipe && !(o.debug & ~(16u | 64u))) launch_encode_pipe<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 1) launch_encode_qw<V, D, Z, 1>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
-  else if (o.encode_qw == 2 && o.encode_waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (o.encode_qw == 2 && c.waves == 8) launch_encode_qw<V, D, Z, 2, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else if (o.encode_qw == 2) launch_encode_qw<V, D, Z, 2>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
-  else if (o.encode_waves == 8 && V == V1234)  // 0124 on small-valued input is faster with the smaller tile
-    launch_encode_qw<V, D, Z, 4, false, V == V1234 ? 8 : kWaves>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (c.waves == 16) launch_encode_qw<V, D, Z, 4, false, 16>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
+  else if (c.waves == 8 && (V == V1234 || o.encode_fresh))  // persistent workgroups: 0124 on small values is faster with the smaller tile
+    launch_encode_qw<V, D, Z, 4, false, 8>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
   else launch_encode_qw<V, D, Z, 4>(o, d_in, count, d_out, prev, ws, ws_bytes, d_written, st);
 }
 template <int V, bool D, bool Z>
@@ -570,10 +591,11 @@ int svbgpu_set_option(const char* name, int value) {
       {"batch_chunk", &o_batch_chunk, [](int v) { return v >= -1 && v <= 64; }},
       {"decode_grid_per_cu", &o_decode_per_cu, [](int v) { return v >= 0; }},
       {"scan_waves", &o_scan_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
-      {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8; }},
+      {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode64_waves", &o_encode64_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
+      {"encode_fresh", &o_encode_fresh, [](int v) { return v == 0 || v == 1; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
-      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 2; }},
+      {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 3; }},
       {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
       {"nt_threshold_mib", &o_nt_threshold_mib, [](int v) { return v >= -1; }},
       {"nt_force", &o_nt_force, [](int v) { return v >= -1 && v <= 3; }},
@@ -753,13 +775,13 @@ int svbgpu_quantize_encode(int variant, const float* d_in, uint32_t count, float
   uint32_t bits;
   std::memcpy(&bits, &scale, 4);
   const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
-  if (o.encode_pipeline) {
+  if (choose_encoder(o, false, count).pipe) {
     if (variant == SVBGPU_1234) launch_encode_pipe<V1234, false, true, 2, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
     else launch_encode_pipe<V0124, false, true, 2, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   } else if (variant == SVBGPU_1234)
     launch_encode_qw<V1234, false, true, 4, true, 8>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   else
-    launch_encode_qw<V0124, false, true, 4, true>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
+    launch_encode_qw<V0124, false, true, 4, true, 8>(o, in, count, d_out, bits, ws, ws_bytes, d_written, S(stream));
   HIP_TRY(hipGetLastError());
   return finish_lookback(ws, S(stream), o.lb_tag2);
 }

@@ -120,21 +120,47 @@ def test_zigzag_fused_and_plain(torch_mod, codec, oracle):
 
 
 def test_encoder_tile_sizes(torch_mod, codec, oracle):
-    """Every tile size of the encoder knob gives the same bytes."""
+    """Every tile shape of the tile-at-a-time encoder (wave tiles per wave, waves per workgroup, a workgroup per
+    tile or persistent workgroups) gives the same bytes."""
     from streamvbyte_amd import DELTA
-    for i, n in enumerate([1, 4097, 16385, 32769, 65537, 262144 + 7, (1 << 20) + 3]):
-        v = gen("width_mix", n, 6000 + i)
+    opt = codec.lib.svbgpu_set_option
+    try:
+        assert opt(b"encode_pipeline", 0) == 0
+        for i, n in enumerate([1, 4097, 16385, 32769, 65537, 262144 + 7, (1 << 20) + 3]):
+            v = gen("width_mix", n, 6000 + i)
+            for variant, flags, prev in ((V1234, 0, 0), (V0124, 0, 0), (V1234, DELTA, 99)):
+                expect = oracle.encode(variant, v, bool(flags), prev)
+                for qw, waves, fresh in ((1, 8, 1), (2, 8, 1), (4, 4, 1), (4, 8, 1), (4, 16, 1), (4, 4, 0), (4, 8, 0), (4, 16, 0)):
+                    opt(b"encode_tile", qw)
+                    opt(b"encode_waves", waves)
+                    opt(b"encode_fresh", fresh)
+                    out, size = codec.encode(to_dev(torch_mod, v), variant=variant, flags=flags, prev=prev)
+                    codec.check()
+                    assert int(size.item()) == expect.size, (n, variant, flags, qw, waves, fresh)
+                    assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags, qw, waves, fresh)
+    finally:
+        opt(b"encode_tile", 4)
+        opt(b"encode_waves", 8)
+        opt(b"encode_fresh", 1)
+        opt(b"encode_pipeline", 3)
+
+
+def test_encoder_chosen_by_size(torch_mod, oracle):
+    """The default picks an encoder by the stream's size: one size from each band of the rule (pipelined, 8 waves
+    with a workgroup per tile, 16 waves, pipelined again for plain input), plain and differential, against the oracle."""
+    import streamvbyte_amd as svb
+    from streamvbyte_amd import DELTA
+    n_max = (1 << 25) + 4099
+    codec = svb.DeviceCodec(max_count=n_max)
+    for n in ((1 << 23) - 5, (1 << 23) + 4097, (1 << 24) + 33, n_max):
+        v = gen("width_mix", n, 6600 + (n & 0xFF))
+        d_v = to_dev(torch_mod, v)
         for variant, flags, prev in ((V1234, 0, 0), (V0124, 0, 0), (V1234, DELTA, 99)):
             expect = oracle.encode(variant, v, bool(flags), prev)
-            for qw, waves in ((1, 8), (2, 8), (4, 4), (4, 8)):
-                codec.lib.svbgpu_set_option(b"encode_tile", qw)
-                codec.lib.svbgpu_set_option(b"encode_waves", waves)
-                out, size = codec.encode(to_dev(torch_mod, v), variant=variant, flags=flags, prev=prev)
-                codec.check()
-                codec.lib.svbgpu_set_option(b"encode_tile", 4)
-                codec.lib.svbgpu_set_option(b"encode_waves", 8)
-                assert int(size.item()) == expect.size, (n, variant, flags, qw, waves)
-                assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags, qw, waves)
+            out, size = codec.encode(d_v, variant=variant, flags=flags, prev=prev)
+            codec.check()
+            assert int(size.item()) == expect.size, (n, variant, flags)
+            assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, variant, flags)
 
 
 def test_cache_policies_and_early_ticket(torch_mod, codec, oracle):
@@ -192,7 +218,7 @@ def test_differential_encode_through_every_encoder(torch_mod, codec, oracle):
                         assert int(size.item()) == expect.size, (n, mode, variant, flags)
                         assert np.array_equal(out[: expect.size].cpu().numpy(), expect), (n, mode, variant, flags)
     finally:
-        lib.svbgpu_set_option(b"encode_pipeline", 1)
+        lib.svbgpu_set_option(b"encode_pipeline", 3)
 
 
 def test_size_and_validate(torch_mod, codec, oracle):

@@ -28,7 +28,7 @@ for n in (1, 1000, 16384, 16385, (1 << 20) + 7, (1 << 22), (1 << 24) + 12345, (1
                 ref = ref[: int(rs.item())].clone()
                 codec.lib.svbgpu_set_option(name, value)
                 got, gs = codec.encode(v, variant=variant, flags=flags)
-                default = {b"encode_pipeline": 1, b"nt_force": -1, b"encode_ticket_early": -1}.get(name, 0)
+                default = {b"encode_pipeline": 3, b"nt_force": -1, b"encode_ticket_early": -1}.get(name, 0)
                 codec.lib.svbgpu_set_option(name, default)
                 codec.check()
                 ok = int(gs.item()) == ref.numel() and torch.equal(got[: ref.numel()], ref)

@@ -31,7 +31,7 @@ for lg in (22, 24, 25, 26, 27, 28):
             opt(b"encode_pipeline", pipe)
             _, ms = event_ms(torch, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), 10)
             row.append(f"{name} p{pipe}: {ms:.4f} ms {nbytes / ms / 1e6 / 8000:.3f}")
-        opt(b"encode_pipeline", 1)
+        opt(b"encode_pipeline", 3)
         del post
     print("  ".join(row), flush=True)
     del codec, enc_out

@@ -35,7 +35,7 @@ for nt in (-1, 0, 3):
     for pipe in (1, 2):
         opt(b"encode_pipeline", pipe)
         show(f"encode pipeline={pipe} nt_force={nt}", enc)
-    opt(b"encode_pipeline", 1)
+    opt(b"encode_pipeline", 3)
     for w in (16, 8, 4):
         opt(b"scan_waves", w)
         show(f"decode scan_waves={w} nt_force={nt}", dec)

@@ -80,12 +80,12 @@ def opt_with(name, value, default, f):
 
 if want("encode"):
     ops["encode"] = (lambda: codec.encode(values, out=enc_out), (4.25 + dbar) * n)
-    ops["encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
+    ops["encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 3, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
     ops["encode_early"] = (opt_with(b"encode_ticket_early", 1, -1, lambda: codec.encode(values, out=enc_out)), (4.25 + dbar) * n)
-    ops["encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(2, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
+    ops["encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 3, enc_with(2, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
 if want("encode_qw"):
     for qw in (1, 2, 4):
-        ops[f"encode_qw{qw}"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(qw, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
+        ops[f"encode_qw{qw}"] = (opt_with(b"encode_pipeline", 0, 3, enc_with(qw, lambda: codec.encode(values, out=enc_out))), (4.25 + dbar) * n)
 if want("delta"):
     g = torch.Generator(device=dev); g.manual_seed(7)
     post = torch.cumsum(torch.randint(0, 32, (n,), generator=g, device=dev, dtype=torch.int64), 0)
@@ -94,7 +94,7 @@ if want("delta"):
     s3 = s3.clone()
     d3 = (int(z3.item()) - keylen) / n
     ops["delta_encode"] = (lambda: codec.encode(post, out=enc_out, flags=svb.DELTA), (4.25 + d3) * n)
-    ops["delta_encode_pipe"] = (opt_with(b"encode_pipeline", 2, 1, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
+    ops["delta_encode_pipe"] = (opt_with(b"encode_pipeline", 2, 3, lambda: codec.encode(post, out=enc_out, flags=svb.DELTA)), (4.25 + d3) * n)
     ops["delta_decode"] = (lambda: codec.decode(s3, n, out=out, flags=svb.DELTA), (4.25 + d3) * n)
 
     ops["delta_decode_w8"] = (opt_with(b"scan_waves", 8, 16, lambda: codec.decode(s3, n, out=out, flags=svb.DELTA)), (4.25 + d3) * n)
@@ -105,7 +105,7 @@ if want("delta"):
         codec.lib.svbgpu_set_option(b"delta_decode_lookback", 1)
     ops["delta_decode_twopass"] = (dd_twopass, (4.25 + d3) * n)
     ops["delta_encode_mixed"] = (lambda: codec.encode(values, out=enc_out, flags=svb.DELTA), (4.25 + dbar) * n)
-    ops["delta_encode_mixed_pipe"] = (opt_with(b"encode_pipeline", 2, 1, lambda: codec.encode(values, out=enc_out, flags=svb.DELTA)), (4.25 + dbar) * n)
+    ops["delta_encode_mixed_pipe"] = (opt_with(b"encode_pipeline", 2, 3, lambda: codec.encode(values, out=enc_out, flags=svb.DELTA)), (4.25 + dbar) * n)
     sm, zm = codec.encode(values, flags=svb.DELTA)
     sm = sm.clone()
     ops["delta_decode_mixed"] = (lambda: codec.decode(sm, n, out=out, flags=svb.DELTA), (int(zm.item()) + 4.0 * n))
@@ -124,9 +124,9 @@ if want("zz"):
     d4 = (int(z4.item()) - (n4 + 3) // 4) / n4
     o4 = out[:n4]
     ops["zz0124_encode"] = (lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
-    ops["zz0124_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 1, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
+    ops["zz0124_encode_nopipe"] = (opt_with(b"encode_pipeline", 0, 3, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
     ops["zz0124_encode_early"] = (opt_with(b"encode_ticket_early", 1, -1, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG)), (4.25 + d4) * n4)
-    ops["zz0124_encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 1, enc_with(2, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG))), (4.25 + d4) * n4)
+    ops["zz0124_encode_q2w8"] = (opt_with(b"encode_pipeline", 0, 3, enc_with(2, lambda: codec.encode(gr, out=enc_out, variant=svb.V0124, flags=svb.ZIGZAG))), (4.25 + d4) * n4)
     ops["zz0124_decode"] = (lambda: codec.decode(s4, n4, out=o4, variant=svb.V0124, flags=svb.ZIGZAG), (4.25 + d4) * n4)
 if want("misc"):
     ops["validate"] = (lambda: codec.validate(stream, size, n), 0.25 * n)
