@@ -111,6 +111,7 @@ struct Options {
   int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8)
   int encode64_waves;    // waves (= wave tiles) per workgroup of k_encode64_lb (4, 8 or 16)
   int encode_fresh;      // k_encode as a workgroup per tile (1) or as persistent workgroups looping over tickets (0)
+  int scan_fresh;        // the same for k_running_sum (measured: 16 waves 0.72 -> 0.67 of peak, 8 waves 0.73; default 0)
   int encode_qw;         // wave tiles per wave in k_encode (1, 2 or 4)
   int batch_lists_per_wave;  // row/wave batched kernels: lists per wave of a launch, 0 = one grid that fills the device
   int batch_chunk;       // batched calls: -1 chunked kernels, streams per wavefront chosen from the batch size;
@@ -127,7 +128,7 @@ struct Options {
   int nt_force;          // -1: by size; 0..3: this policy whatever the size (bit 0 loads, bit 1 stores)
   unsigned lb_tag2 = 0;  // not a knob: the look-back tag of the running call (LbWords::tag2), set by prepare_lookback
 };
-std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8}, o_encode64_waves{8}, o_encode_fresh{1},
+std::atomic<int> o_scan_waves{16}, o_decode_per_cu{0}, o_decode_shortcut{1}, o_delta_lookback{1}, o_encode_waves{8}, o_encode64_waves{8}, o_encode_fresh{1}, o_scan_fresh{0},
     o_encode_qw{4}, o_encode_pipeline{3}, o_encode_ticket_early{-1}, o_batch_lists_per_wave{8}, o_batch_chunk{-1}, o_debug{0}, o_zigzag_piece{0x7FFFFFFF}, o_host_cpu_cutoff{1 << 16}, o_host_serialize{1},
     o_host_stage_pageable{1}, o_nt_threshold_mib{128}, o_nt_force{-1}, o_host_pointers_only{0};
 inline Options options() {
@@ -140,6 +141,7 @@ inline Options options() {
   o.encode_waves = o_encode_waves.load(rl);
   o.encode64_waves = o_encode64_waves.load(rl);
   o.encode_fresh = o_encode_fresh.load(rl);
+  o.scan_fresh = o_scan_fresh.load(rl);
   o.encode_qw = o_encode_qw.load(rl);
   o.encode_pipeline = o_encode_pipeline.load(rl);
   o.encode_ticket_early = o_encode_ticket_early.load(rl);
@@ -594,6 +596,7 @@ int svbgpu_set_option(const char* name, int value) {
       {"encode_waves", &o_encode_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode64_waves", &o_encode64_waves, [](int v) { return v == 4 || v == 8 || v == 16; }},
       {"encode_fresh", &o_encode_fresh, [](int v) { return v == 0 || v == 1; }},
+      {"scan_fresh", &o_scan_fresh, [](int v) { return v == 0 || v == 1; }},
       {"encode_tile", &o_encode_qw, [](int v) { return v == 1 || v == 2 || v == 4; }},
       {"encode_pipeline", &o_encode_pipeline, [](int v) { return v >= 0 && v <= 3; }},
       {"encode_ticket_early", &o_encode_ticket_early, [](int v) { return v >= -1 && v <= 1; }},
@@ -903,14 +906,15 @@ int svbgpu_zigzag_delta_decode(const uint32_t* d_in, int32_t* d_out, size_t n, i
   const u32 n_tiles8 = (u32)((L.n_wt + 31) / 32);  // 8 waves of 4 wave tiles per workgroup
   const u32 n_tiles16 = (u32)((L.n_wt + 63) / 64);
   const int scan_waves = options().scan_waves;
+  const bool fresh = options().scan_fresh;  // a workgroup per tile instead of persistent workgroups
   if (scan_waves == 16)
     SVB_NT_SWITCH_03(nt_policy(options(), 4ull * count, 4ull * count), NTV,
-                     hipLaunchKernelGGL((k_running_sum<true, 16, NTV>), dim3(stream_grid(n_tiles16, 1)), dim3(1024), 0,
+                     hipLaunchKernelGGL((k_running_sum<true, 16, NTV>), dim3(fresh ? n_tiles16 : stream_grid(n_tiles16, 1)), dim3(1024), 0,
                                         S(stream), d_in, reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev,
                                         n_tiles16, ws_hdr_slot(ws, tag2),
                                         lb_words(ws, L, tag2)))
   else if (scan_waves == 8)
-    hipLaunchKernelGGL((k_running_sum<true, 8>), dim3(stream_grid(n_tiles8, 2)), dim3(512), 0, S(stream), d_in,
+    hipLaunchKernelGGL((k_running_sum<true, 8>), dim3(fresh ? n_tiles8 : stream_grid(n_tiles8, 2)), dim3(512), 0, S(stream), d_in,
                        reinterpret_cast<uint32_t*>(d_out), count, (uint32_t)prev, n_tiles8, ws_hdr_slot(ws, tag2),
                        lb_words(ws, L, tag2));
   else

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restric
   __shared__ u32 s_prefix;
   __shared__ u32 s_tile;
   const int lane = lane_id(), wave = wave_id();
-  // persistent workgroups: tiles are drawn from the ticket until none is left
+  // tiles are drawn from the ticket: by persistent workgroups until none is left, or one by each workgroup of a
+  // launch that has a workgroup per tile
   for (;;) {
   if (threadIdx.x == 0) s_tile = atomicAdd(&hdr->ticket, 1u);
   __syncthreads();
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_running_sum(const u32* __restric
         store_group(out, wave_first + (u64)q * kWtInts + 4u * (j * 64 + lane), count, r);
       }
   }
+  if (gridDim.x >= n_tiles) break;  // launched with a workgroup per tile: every ticket has its drawer
   }
 }
 

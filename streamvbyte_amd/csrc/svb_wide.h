@@ -243,6 +243,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_encode64_lb(const u64* __restric
     u64 doff = s_prefix;
     for (int w = 0; w < wave; ++w) doff += s_wave_tot[w];
     if (wt_first < count) emit_wavetile64<NT>(S, out, keylen, count, wt, wt_first, doff, lane, v, key4, lens4);
+    if (gridDim.x >= n_tiles) break;  // launched with a workgroup per tile: every ticket has its drawer
   }
 }
 

@@ -134,6 +134,8 @@ if want("misc"):
     ops["zigzag_enc"] = (lambda: codec.zigzag(values, "encode", out=out), 8.0 * n)
     tmpz = torch.empty(n, dtype=torch.int32, device=dev)
     ops["zigzag_delta_dec"] = (lambda: codec.zigzag(values, "delta_decode", out=tmpz), 8.0 * n)
+    ops["zigzag_delta_dec_fresh"] = (opt_with(b"scan_fresh", 1, 0, lambda: codec.zigzag(values, "delta_decode", out=tmpz)), 8.0 * n)
+    ops["zigzag_delta_dec_fresh8"] = (opt_with(b"scan_waves", 8, 16, opt_with(b"scan_fresh", 1, 0, lambda: codec.zigzag(values, "delta_decode", out=tmpz))), 8.0 * n)
 if want("intersect"):
     # dense postings against every 8th of their own values: as a sorted array, and as a delta-coded stream
     gi = torch.Generator(device=dev); gi.manual_seed(5)
