@@ -438,9 +438,9 @@ void launch_encode_qw(const Options& o, const uint32_t* d_in, uint32_t count, ui
     SVB_NT_SWITCH_013(nt_policy_encode(o, V, count), NTV,
                       hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW, (QW == 4 ? NTV : 0)>), dim3(grid), dim3(NW * 64), 0,
                                          st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps))
-  else if (full_tiles)
-    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW>), dim3(grid), dim3(NW * 64),
-                       0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug, stamps);
+  else if (full_tiles)  // the smaller tiles: experiments only (option encode_tile)
+    hipLaunchKernelGGL((k_encode<V, D, Z, QW, true, QUANT, NW>), dim3(o.encode_fresh ? full_tiles : grid), dim3(NW * 64),
+                       0, st, d_in, count, full_tiles, d_out, prev, h, status, d_written, o.debug | (o.encode_fresh ? 8u : 0u), stamps);
   if (ragged)  // the one tile that runs past the end of the stream: same look-back words
     hipLaunchKernelGGL((k_encode<V, D, Z, QW, false, QUANT, NW>), dim3(1), dim3(NW * 64), 0, st, d_in, count, full_tiles,
                        d_out, prev, h, status, d_written, o.debug, stamps);

@@ -33,11 +33,14 @@ for name, variant, flags in (("1234", svb.V1234, 0), ("0124+zz", svb.V0124, svb.
         _, z = f()
         nbytes = int(z.item()) + 4.0 * n
         row = [f"{name:11s} 2^{lg}"]
-        for label, pipe, fresh, waves in (("pipe", 2, 1, 8), ("8w fresh", 0, 1, 8), ("16w", 0, 1, 16), ("8w persistent", 0, 0, 8), ("4w fresh", 0, 1, 4)):
-            opt(b"encode_pipeline", pipe); opt(b"encode_fresh", fresh); opt(b"encode_waves", waves)
+        shapes = (("pipe", 2, 1, 8, 4), ("8w fresh", 0, 1, 8, 4), ("16w", 0, 1, 16, 4), ("8w persistent", 0, 0, 8, 4), ("4w fresh", 0, 1, 4, 4))
+        if os.environ.get("SMALL_TILES"):
+            shapes = (("8w fresh", 0, 1, 8, 4), ("8w x 2 wave tiles fresh", 0, 1, 8, 2), ("4w x 2 fresh", 0, 1, 4, 2), ("4w x 1 fresh", 0, 1, 4, 1))
+        for label, pipe, fresh, waves, qw in shapes:
+            opt(b"encode_pipeline", pipe); opt(b"encode_fresh", fresh); opt(b"encode_waves", waves); opt(b"encode_tile", qw)
             _, ms = event_ms(torch, f, 10, warmup=60)
             row.append(f"{label} {ms * 1e3:8.1f} us {nbytes / ms / 1e6 / 8000:.3f}")
-        opt(b"encode_pipeline", 3); opt(b"encode_fresh", 1); opt(b"encode_waves", 8)
+        opt(b"encode_pipeline", 3); opt(b"encode_fresh", 1); opt(b"encode_waves", 8); opt(b"encode_tile", 4)
         codec.check()
         print("  ".join(row), flush=True)
         del codec, v, out
