@@ -21,8 +21,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log2n", type=int, default=28)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--only", default="")
+ap.add_argument("--skip", default="", help="groups to leave out (the profile run skips 'ablate': its timing-only launches share kernel names with the real ones)")
 a = ap.parse_args()
 only = set(a.only.split(",")) if a.only else None
+skip = set(a.skip.split(",")) if a.skip else set()
 n = 1 << a.log2n
 dev = "cuda:0"
 codec = svb.DeviceCodec(n, dev)
@@ -30,7 +32,7 @@ ops = {}
 
 
 def want(name):
-    return only is None or name in only
+    return name not in skip and (only is None or name in only)
 
 
 values = gen_width_mix(torch, n, 1, dev)

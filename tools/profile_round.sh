@@ -11,9 +11,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $ROOT/bench.py > $OUT/prof_bench.log 2>&1
 echo "bench trace done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_micro -- python3 $ROOT/tools/microbench.py --rounds 2 > $OUT/prof_micro.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_micro -- python3 $ROOT/tools/microbench.py --rounds 2 --skip ablate > $OUT/prof_micro.log 2>&1
 echo "microbench trace done"
-timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 $ROOT/tools/microbench.py --rounds 2 > $OUT/prof_fetch.log 2>&1
+timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 $ROOT/tools/microbench.py --rounds 2 --skip ablate > $OUT/prof_fetch.log 2>&1
 echo "fetch pass done"
-timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 $ROOT/tools/microbench.py --rounds 2 > $OUT/prof_write.log 2>&1
+timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 $ROOT/tools/microbench.py --rounds 2 --skip ablate > $OUT/prof_write.log 2>&1
 echo "write pass done"
