@@ -331,7 +331,7 @@ void launch_delta_decode(const Options& o, const uint8_t* d_in, uint32_t* d_out,
     else
       hipLaunchKernelGGL((k_delta_decode<V1234, false, 8, 3, true>), dim3((unsigned)((L.n_wt + 31) / 32)), dim3(512), 0, st,
                          d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws), lbw, d_consumed, stamps);
-  } else if (o.scan_waves == 16 && count >= (1u << 23))  // shorter streams do better with more, smaller tiles
+  } else if (o.scan_waves == 16 && count >= (3u << 22))  // shorter streams do better with more, smaller tiles (2^23 values: 8 waves 7-8 % ahead, 2^24: 16 waves 12-18 %)
     SVB_NT_SWITCH_023(nt_policy(o, min_stream_bytes(V, count), 4ull * count), NTV,
                       hipLaunchKernelGGL((k_delta_decode<V, ZZ, 16, NTV>), dim3((unsigned)((L.n_wt + 63) / 64)), dim3(1024),
                                          0, st, d_in, d_out, count, prev, ws_dir(ws, L), ws_hdr(ws),

@@ -328,9 +328,10 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
 // QUANT: the input holds float32; every value becomes (int32)rintf(x * scale) first
 // (scale travels as the bits of `prev`, which only DELTA uses otherwise) -- the
 // quantise step of gradient compression fused into the encoder's load.
-// FRESH: the launch has a workgroup per full tile, each draws one ticket and ends after its tile (the
-// dispatcher refills the slot); else persistent workgroups loop over tickets.
-template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves, int NT = 0, bool FRESH = false>
+// dbg bit 3 (set by the launch code, not a diagnostic): the launch has a workgroup per full tile, each draws
+// one ticket and ends after its tile (the dispatcher refills the slot); else persistent workgroups loop
+// over tickets.  A run-time flag, so that both forms are the same code.
+template <int V, bool DELTA, bool ZZ, int QW, bool FULL, bool QUANT = false, int NW = kWaves, int NT = 0>
 __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V1234 ? 4 : 5)) void k_encode(
     const u32* __restrict__ in, u32 count, u32 n_tiles, u8* __restrict__ out, u32 prev,
     WsHeader* __restrict__ hdr, LbWords lb, u64* __restrict__ written, u32 dbg,
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
   __shared__ u32 s_tile;
 
   const int lane = lane_id(), wave = wave_id();
-  // FULL: a workgroup draws tiles from the ticket -- one (FRESH) or until the n_tiles full tiles
+  // FULL: a workgroup draws tiles from the ticket -- one (dbg bit 3) or until the n_tiles full tiles
   // are taken.  !FULL: the one ragged tile, index n_tiles, one workgroup.
   for (;;) {
   u32 tile = n_tiles;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
   }
   }
   if (stamps && threadIdx.x == 0) stamps[5 * (u64)tile + 3] = __builtin_amdgcn_s_memrealtime();
-  if (!FULL || FRESH || (dbg & 8u)) break;  // dbg bit 3: this launch has a workgroup per tile
+  if (!FULL || (dbg & 8u)) break;  // dbg bit 3: this launch has a workgroup per tile
   }
 }
 
