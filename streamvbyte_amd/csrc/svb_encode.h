@@ -320,6 +320,9 @@ __device__ __forceinline__ void zero_absent(uint4& c, u64 first, u64 count) {
   }
 }
 
+#ifndef SVB_ENCODE_LB_KT
+#define SVB_ENCODE_LB_KT 2  // tile words polled per lane in k_encode's look-back (A/B at 2^28 values, a workgroup per tile: 1 / 2 / 4 = 0.664 / 0.667 / 0.605 of peak on mixed widths, 0.636 / 0.655 / 0.660 on dense postings)
+#endif
 // k_encode<.., FULL=true> handles the tiles that lie wholly inside the stream
 // (one workgroup each, no bounds logic); the one ragged tile at the end, if any,
 // is a second single-workgroup launch of the FULL=false instantiation on the
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, !FULL ? 1 : (NW == 8 || QW > 2 || V != V12
     u64 excl = 0;
     u32 rounds = 0;
     if (!(dbg & 1u)) {
-      excl = lb2_exclusive_prefix(lb, tile, tile_tot, lane, &hdr->error, &rounds);
+      excl = lb2_exclusive_prefix<SVB_ENCODE_LB_KT>(lb, tile, tile_tot, lane, &hdr->error, &rounds);
     } else {
       excl = (u64)tile * (kTileInts * 5 / 2);  // timing experiment: no look-back, plausible (wrong) offsets
       if (dbg & 4u) {                          // ... after idling about as long as a look-back takes
