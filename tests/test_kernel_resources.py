@@ -33,3 +33,12 @@ def test_hot_kernels_do_not_spill():
             assert rows[k]["occ"] >= 7, (k, rows[k])   # seven workgroups of four waves per CU (the LDS limit)
         if k.startswith("k_encode_batch2<"):
             assert rows[k]["occ"] >= 6, (k, rows[k])   # two tiles of values in registers took it to four and cost 15 %
+    # the tile-at-a-time encoder on full tiles of four wave tiles a wave (the default from 2^27 values up, and for
+    # differential input from 2^25): two workgroups of eight waves per CU, nothing spilled
+    full_tile = [k for k in rows if re.match(r"(svb::)?k_encode<[01], (true|false), (true|false), 4, true, ", k)]
+    assert len(full_tile) >= 16, sorted(rows)[:40]
+    for k in full_tile:
+        assert rows[k]["scratch"] == 0 and rows[k]["occ"] >= 4, (k, rows[k])
+    for k in rows:
+        if re.match(r"(svb::)?k_(stream_intersect|intersect_batch|delta_intersect|size_batch)<", k):
+            assert rows[k]["scratch"] == 0, (k, rows[k])
