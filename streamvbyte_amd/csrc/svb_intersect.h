@@ -482,8 +482,11 @@ __global__ __launch_bounds__(kBlock) void k_stream_bounds(const u32* __restrict_
   range[w] = make_uint2(x, lo);
 }
 
+// Five waves per SIMD (96 VGPRs, two or three dwords spilled): the kernel waits on chains of dependent loads,
+// and a fifth wave is worth 8-10 % (2^27 postings against as many: 0.577 -> 0.535 ms); a sixth (80 VGPRs, ten
+// dwords spilled) gives it back.
 template <int VA, int VB, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void k_stream_intersect(
+__global__ __launch_bounds__(NW * 64, 5) void k_stream_intersect(
     const u8* __restrict__ a_in, u32 a_count, Dir a_dir, const u32* __restrict__ a_vpre,
     const u32* __restrict__ a_blk, const u8* __restrict__ b_in, u32 b_count, Dir b_dir,
     const u32* __restrict__ b_vpre, const u32* __restrict__ b_blk, const uint2* __restrict__ range,

@@ -40,5 +40,7 @@ def test_hot_kernels_do_not_spill():
     for k in full_tile:
         assert rows[k]["scratch"] == 0 and rows[k]["occ"] >= 4, (k, rows[k])
     for k in rows:
-        if re.match(r"(svb::)?k_(stream_intersect|intersect_batch|delta_intersect|size_batch)<", k):
+        if re.match(r"(svb::)?k_(intersect_batch|delta_intersect|size_batch)<", k):
             assert rows[k]["scratch"] == 0, (k, rows[k])
+        if re.match(r"(svb::)?k_stream_intersect<", k):  # five waves per SIMD at the price of two or three spilled dwords
+            assert rows[k]["scratch"] <= 16 and rows[k]["occ"] >= 5, (k, rows[k])
