@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Batched encode / decode of the posting-list mix (lists of log-uniform length 1..4096) under
 different grids: python tools/batch_mix.py [lists_per_wave ...]   (0 = persistent grid)
-SVB_NT_FORCE=<0..3> in the environment forces a cache policy (default: the library's own choice)."""
+SVB_NT_FORCE=<0..3> in the environment forces a cache policy (default: the library's own choice);
+MIX_MIN / MIX_MAX / MIX_LISTS restrict the lengths to a part of the mix (default 1 / 4096 / 2^20 lists)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +10,10 @@ sys.path.insert(0, ROOT)
 import torch
 import streamvbyte_amd as svb
 dev = "cuda:0"
-nl = 1 << 20
+nl = int(os.environ.get("MIX_LISTS", 1 << 20))
 rng = np.random.default_rng(5)
-lens = np.floor(np.exp(rng.uniform(0, np.log(4096), nl))).astype(np.int64)
+lo, hi = int(os.environ.get("MIX_MIN", 1)), int(os.environ.get("MIX_MAX", 4096))
+lens = np.floor(np.exp(rng.uniform(np.log(lo), np.log(hi), nl))).astype(np.int64)
 start = np.concatenate([[0], np.cumsum(lens)])
 n = int(start[-1])
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -46,5 +48,5 @@ for k in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 8, 16]:
     te = t(lambda: codec.encode_batch(vals, voff, bbuf, boff, counts, None, flags=svb.DELTA, sizes=sizes))
     td = t(lambda: codec.decode_batch(bbuf, boff, back, voff, counts, None, flags=svb.DELTA))
     assert torch.equal(back, vals)
-    print(f"lists per wave {k:3d}: encode {te:6.3f} ms {ab / te / 1e6 / 8000:5.3f} of peak   decode {td:6.3f} ms {ab / td / 1e6 / 8000:5.3f} of peak")
+    print(f"{nl} lists of {lo}..{hi} values, {n} in all; lists per wave {k:3d}: encode {te:6.3f} ms {ab / te / 1e6 / 8000:5.3f} of peak   decode {td:6.3f} ms {ab / td / 1e6 / 8000:5.3f} of peak")
 codec.lib.svbgpu_set_option(b"batch_lists_per_wave", 0)
