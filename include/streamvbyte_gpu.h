@@ -96,13 +96,15 @@ int svbgpu_build_has(const char *feature);
  *   "encode_tile" = 1 | 2 | 4   wave tiles (1024 values) each wavefront of the
  *                               one-tile-at-a-time encoder carries through the
  *                               look-back (default 4)
- *   "encode_waves" = 4 | 8      wavefronts per workgroup of the encoders
- *                               (default 8; the 0124 encoder always uses 4)
+ *   "encode64_waves" = 4|8|16   wavefronts (one wave tile each) per workgroup of
+ *                               the 64-bit encoder (default 8)
  *   "scan_waves" = 4 | 8 | 16   wavefronts per workgroup of the running sum
  *                               behind svbgpu_zigzag_delta_decode and of the
  *                               single-pass differential decoder (default 16:
  *                               a tile of 65 536 values per look-back; streams
- *                               below 2^23 values are decoded with 8)
+ *                               below 3 * 2^22 values are decoded with 8)
+ *   "scan_fresh" = 0|1          running sum: 0 (default) persistent workgroups that
+ *                               loop over tiles, 1 a workgroup per tile (slower)
  *   "decode_shortcut" = 0|1     1 (default): the plain decoder copies wave tiles
  *                               (1024 values) whose keys are all zero straight
  *                               from their data bytes; 0: one code path for all

@@ -108,7 +108,7 @@ struct Options {
   int decode_per_cu;     // decoders: workgroups per CU of a persistent grid, 0 = a workgroup per 4 wave tiles
   int decode_shortcut;   // plain decoder: shortcut for wave tiles of all-zero keys
   int delta_lookback;    // 1: single-pass look-back differential decoder, 0: two streaming passes
-  int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4 or 8)
+  int encode_waves;      // waves per workgroup of k_encode when a wave carries 4 wave tiles (4, 8 or 16)
   int encode64_waves;    // waves (= wave tiles) per workgroup of k_encode64_lb (4, 8 or 16)
   int encode_fresh;      // k_encode as a workgroup per tile (1) or as persistent workgroups looping over tickets (0)
   int scan_fresh;        // the same for k_running_sum (measured: 16 waves 0.72 -> 0.67 of peak, 8 waves 0.73; default 0)
