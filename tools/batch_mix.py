@@ -2,7 +2,8 @@
 """Batched encode / decode of the posting-list mix (lists of log-uniform length 1..4096) under
 different grids: python tools/batch_mix.py [lists_per_wave ...]   (0 = persistent grid)
 SVB_NT_FORCE=<0..3> in the environment forces a cache policy (default: the library's own choice);
-MIX_MIN / MIX_MAX / MIX_LISTS restrict the lengths to a part of the mix (default 1 / 4096 / 2^20 lists)."""
+MIX_MIN / MIX_MAX / MIX_LISTS restrict the lengths to a part of the mix (default 1 / 4096 / 2^20 lists);
+MIX_ROUND rounds them up to a multiple (aligned list starts)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +15,8 @@ nl = int(os.environ.get("MIX_LISTS", 1 << 20))
 rng = np.random.default_rng(5)
 lo, hi = int(os.environ.get("MIX_MIN", 1)), int(os.environ.get("MIX_MAX", 4096))
 lens = np.floor(np.exp(rng.uniform(np.log(lo), np.log(hi), nl))).astype(np.int64)
+rnd = int(os.environ.get("MIX_ROUND", 1))  # lengths rounded up to a multiple: every list then starts on that alignment
+lens = (lens + rnd - 1) // rnd * rnd
 start = np.concatenate([[0], np.cumsum(lens)])
 n = int(start[-1])
 g = torch.Generator(device=dev); g.manual_seed(1)
