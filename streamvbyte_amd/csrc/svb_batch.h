@@ -255,6 +255,13 @@ constexpr u32 kFlatMax = 256;  // values; such a stream has at most 64 groups
 #define SVB_BATCH_WAVES 4
 #endif
 constexpr int kBatchWaves = SVB_BATCH_WAVES;
+// 1: the long part of the chunked decoder stores the whole wave tiles of a stream whose values do not start on a
+// 64-byte boundary as aligned quarters, by way of the LDS image (see there).  Same box, alternating libraries, on
+// 2^20 posting lists laid back to back: 0.508-0.510 -> 0.519-0.523 of peak; the long lists alone 0.521 -> 0.543.
+// The stream's last, partial tile taken the same way added nothing and is not built.
+#ifndef SVB_BATCH_REALIGN
+#define SVB_BATCH_REALIGN 1
+#endif
 
 // Directory entry of a short stream, compacted to the front of the wave's LDS.
 struct __align__(16) FlatEnt {
@@ -421,6 +428,10 @@ __device__ __forceinline__ void decode_batch2_body(
   u32 wt = 0;
   u64 doff = 0;
   u32 w_raw = load_keys(in, keylen);
+#if SVB_BATCH_REALIGN
+  bool have_carry = false;  // wave-uniform: cr holds values of the current stream that are not stored yet
+  u32 cr = 0;
+#endif
   for (;;) {
     const u32 w = w_raw;
     const u32 keys_left = keylen - wt * (u32)kWtKeys;  // from this wave tile on
@@ -455,11 +466,54 @@ __device__ __forceinline__ void decode_batch2_body(
       // a whole wave tile (wave-uniform): the length is a constant, so every bounds check of the
       // tile decoder and of the stores folds away
       doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, (u32)kWtInts, in + keylen + doff, lane, S, v);
+#if SVB_BATCH_REALIGN
+      const u32 a = (u32)(((uintptr_t)out >> 2) & 15u);  // dwords from the 64-byte boundary below the stream's first value
+      if (a != 0u) {
+        // The stream's values do not start on a 64-byte boundary: a quarter's 1 KiB would straddle one in every
+        // four lanes.  The tile's values take a trip through the (now free) LDS image, displaced by `a` dwords,
+        // and leave as four ALIGNED quarters; the `a` values that hang over wait in a register for the next tile.
+        uint4 c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = integrate(v[j]);
+        u32* B = reinterpret_cast<u32*>(S.data);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32* q = B + a + 256u * j + 4u * (u32)lane;
+          q[0] = c[j].x; q[1] = c[j].y; q[2] = c[j].z; q[3] = c[j].w;
+        }
+        if (have_carry && (u32)lane < a) B[lane] = cr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u32* o = out + int0 - a;  // 64-byte aligned; below the stream's first value in its first tile
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 p = 256u * k + 4u * (u32)lane;
+          const uint4 q = *reinterpret_cast<const uint4*>(B + p);
+          if (k == 0 && !have_carry && p < a) {  // the stream's first tile: positions below a lie before the stream
+            if (p + 1u >= a) o[p + 1u] = q.y;
+            if (p + 2u >= a) o[p + 2u] = q.z;
+            if (p + 3u >= a) o[p + 3u] = q.w;
+          } else {
+            st_stream16<(NT & kNtStores) != 0>(o + p, q);
+          }
+        }
+        cr = lane < 16 ? B[1024 + lane] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        have_carry = true;
+        if (last_tile && (u32)lane < a) out[int0 + kWtInts - a + (u32)lane] = cr;  // the stream ends with this tile
+      } else
+#endif
+      {
       u32* o = out + int0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) st_stream16<(NT & kNtStores) != 0>(o + 4u * (u32)(j * 64 + lane), integrate(v[j]));
+      }
     } else {
       const u32 nints = (u32)((u64)count - int0);
+#if SVB_BATCH_REALIGN
+      const u32 a = (u32)(((uintptr_t)out >> 2) & 15u);
+      if (have_carry && (u32)lane < a) out[int0 - a + (u32)lane] = cr;  // what hung over the last whole tile
+#endif
       doff += decode_wavetile<V, ZZ, true, false, (NT & kNtLoads) != 0>(w, nints, in + keylen + doff, lane, S, v);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -482,6 +536,9 @@ __device__ __forceinline__ void decode_batch2_body(
     keylen = (u32)(((u64)count + 3) >> 2);
     wt = 0;
     doff = 0;
+#if SVB_BATCH_REALIGN
+    have_carry = false;
+#endif
   }
 }
 

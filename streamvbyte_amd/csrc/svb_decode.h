@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_key_sums(const u8* __restrict__ in, u3
 // reads per group instead of one dword cost k_decode 8 %.)
 struct __align__(16) WaveLds {
   u32 ent[kWtKeys];
-  u8 data[kWtDataMax + 48];  // +16 alignment slack, +16 partial chunk, +slack for 8-byte over-read
+  u8 data[kWtDataMax + 64];  // +16 alignment slack, +16 partial chunk, +slack for 8-byte over-read; the batched decoder also parks a tile's 1024 values plus 16 in it
 };
 
 // Blocked phase: lane holds keys 4l..4l+3 in w.  Writes the 4 entries of those

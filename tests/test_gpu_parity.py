@@ -425,6 +425,55 @@ def test_batched_cache_policies(torch_mod, codec, oracle):
         lib.svbgpu_set_option(b"nt_threshold_mib", 128)
 
 
+def test_batched_decode_any_start_alignment(torch_mod, codec, oracle):
+    """Lists whose values start at every distance from a 64-byte boundary, with gaps of sentinel values between
+    them: the decoder (which stores the whole tiles of a long list as aligned quarters, displaced through LDS, and
+    the values that hang over one tile later) writes every value of every list and nothing else.  Lengths
+    around the tile borders, exact multiples of a tile included."""
+    from streamvbyte_amd import DELTA, ZIGZAG, streamvbyte_max_compressedbytes
+    torch = torch_mod
+    rng = np.random.default_rng(9091)
+    lens = [1024, 2048, 1025, 3077, 257, 1023, 4096, 1, 300, 2047, 5120, 1039]
+    counts, voff, pos = [], [], 0
+    for a in range(16):
+        for k, n in enumerate(lens):
+            gap = 16 + (a - pos) % 16 if k == 0 else int(rng.integers(0, 3)) * 16 + int(rng.integers(1, 4)) * (k % 2)
+            pos += gap
+            if k == 0:
+                assert pos % 16 == a
+            counts.append(n)
+            voff.append(pos)
+            pos += n
+    total = pos + 64
+    counts = np.array(counts, dtype=np.uint32)
+    voff = np.array(voff, dtype=np.uint64)
+    ns = counts.size
+    assert {int(v) % 16 for v, c in zip(voff, counts) if c >= 1024} == set(range(16))
+    prevs = rng.integers(0, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)
+    cap = np.array([streamvbyte_max_compressedbytes(int(c)) for c in counts], dtype=np.uint64)
+    boff = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+    SENT = np.uint32(0xA5A5A5A5)
+    values = np.full(total, SENT, dtype=np.uint32)
+    for s in range(ns):
+        values[int(voff[s]): int(voff[s]) + int(counts[s])] = GENERATORS["postings" if s % 3 else "width_mix"](rng, int(counts[s]))
+    d_values = to_dev(torch, values)
+    d_voff = torch.from_numpy(voff.astype(np.int64)).cuda()
+    d_boff = torch.from_numpy(boff[:-1].astype(np.int64)).cuda()
+    d_counts, d_prevs = to_dev(torch, counts), to_dev(torch, prevs)
+    for variant, flags in ((V1234, DELTA), (V1234, 0), (V0124, ZIGZAG | DELTA)):
+        buf = torch.zeros(int(boff[-1]) + 16, dtype=torch.uint8, device="cuda:0")
+        sizes = codec.encode_batch(d_values, d_voff, buf, d_boff, d_counts, d_prevs, variant=variant, flags=flags)
+        h_sizes, h_buf = sizes.cpu().numpy(), buf.cpu().numpy()
+        for s in range(ns):
+            e = _expected_stream(oracle, variant, flags, values[int(voff[s]): int(voff[s]) + int(counts[s])],
+                                 int(prevs[s]) if flags & DELTA else 0)
+            assert h_sizes[s] == e.size and np.array_equal(h_buf[int(boff[s]): int(boff[s]) + e.size], e), (s, counts[s])
+        back = torch.full((total,), int(SENT) - (1 << 32), dtype=torch.int32, device="cuda:0")
+        used = codec.decode_batch(buf, d_boff, back, d_voff, d_counts, d_prevs, variant=variant, flags=flags)
+        assert np.array_equal(used.cpu().numpy(), h_sizes)
+        assert np.array_equal(to_np(back, np.uint32), values), (variant, flags)  # the lists AND the gaps between them
+
+
 def test_batched_directory_in_any_order(torch_mod, codec, oracle):
     """The directory of a batch need not follow the memory layout: streams listed in reverse and in
     shuffled order (the device's guess at the batch's size, taken from the first and last entry, is then
