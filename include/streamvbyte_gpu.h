@@ -384,10 +384,10 @@ int svbgpu_decode64_batch(unsigned flags, const uint8_t *d_bytes, const uint64_t
  * are packed a group of four values per lane across stream borders, longer
  * ones go a wave tile (1024 values) at a time.  That suits streams of up to
  * some 10^5 values; give longer ones to the single-stream calls above, which
- * spread one stream over the whole device.  d_value_off may be anything;
- * streams whose values start on a 64-byte boundary (offsets that are
- * multiples of 16) decode 5-9 % faster, because a wavefront's stores then
- * cover whole 64-byte segments.
+ * spread one stream over the whole device.  d_value_off may be anything:
+ * the decoder stores the whole tiles of a long stream as 64-byte-aligned
+ * blocks wherever its values start; streams that start on such a boundary
+ * themselves (offsets that are multiples of 16) still decode about 2 % faster.
  */
 int svbgpu_encode_batch(int variant, unsigned flags, const uint32_t *d_values,
                         const uint64_t *d_value_off, uint8_t *d_bytes, const uint64_t *d_byte_off,
