@@ -3,7 +3,7 @@
 different grids: python tools/batch_mix.py [lists_per_wave ...]   (0 = persistent grid)
 SVB_NT_FORCE=<0..3> in the environment forces a cache policy (default: the library's own choice);
 MIX_MIN / MIX_MAX / MIX_LISTS restrict the lengths to a part of the mix (default 1 / 4096 / 2^20 lists);
-MIX_ROUND rounds them up to a multiple (aligned list starts)."""
+MIX_ROUND rounds them up to a multiple (aligned list starts), MIX_BALIGN does the same for the lists' bytes."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +28,8 @@ del gaps
 counts = torch.from_numpy(lens.astype(np.int32)).to(dev)
 voff = first
 cap = (lens + 3) // 4 + 4 * lens + 16
+bal = int(os.environ.get("MIX_BALIGN", 1))  # room per list rounded up to a multiple: every list's bytes then start on that alignment
+cap = (cap + bal - 1) // bal * bal
 boff = torch.from_numpy(np.concatenate([[0], np.cumsum(cap)])[:-1]).to(dev)
 bbuf = torch.empty(int(cap.sum()) + 16, dtype=torch.uint8, device=dev)
 back = torch.empty_like(vals)
